@@ -1,0 +1,66 @@
+/*
+ * pt_host.h -- C entry points of the host scene pipeline (libpt_host.so), for callers that are not
+ * C++ (the Python tests and bench.py load it with ctypes).  It wraps the host mirror of the
+ * reference's scene code -- sampleScenes.cpp:9-143 (presets), geometry.cpp:11-67 / scene.cpp:16-41
+ * (BLAS / TLAS build with the bvh.hpp builder), input.cpp:12-147 (loaders) -- and hands out the
+ * flattened ptx_scene_desc that ptx_create (ptx_backend.h) consumes.  No GPU code is involved.
+ */
+#ifndef PT_HOST_H
+#define PT_HOST_H
+
+#include <stdint.h>
+
+#include "ptx_backend.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pth_scene pth_scene;
+
+typedef struct pth_info {
+  uint32_t triangles_per_mesh;   /* README.md:56-60 "triangles per mesh" (geometry 0) */
+  uint32_t blas_nodes;           /* README.md:56-60 "BLAS" (geometry 0) */
+  uint32_t tlas_nodes;           /* README.md:56-60 "TLAS" */
+  uint32_t instances;
+  uint32_t blas_depth, tlas_depth;
+  uint32_t blas_max_leaf, tlas_max_leaf;
+  uint32_t stand_in_geometry;    /* 1: procedural bust instead of models/bust-of-menelaus.stl */
+  uint32_t stand_in_environment; /* 1: analytic sky instead of the HDR */
+  double blas_build_s, tlas_build_s;
+} pth_info;
+
+/* getScene(sampleScene, ...) + scene.completeScene() + flatten.  preset: 0 THREE_STL, 1 SCATTER_STL,
+ * 2 OBJ (sampleScenes.hpp:6-8).  models_dir holds bust-of-menelaus.stl and viking-room/;
+ * env_path is the Radiance HDR (either may be absent: deterministic stand-ins are used and
+ * reported in pth_info).  scatter_instances: 0 = 10,000 as the reference.  Returns 0 / -1. */
+int pth_scene_create(int preset, const char* models_dir, const char* env_path,
+                     uint32_t scatter_instances, uint32_t sky_width, uint32_t sky_height,
+                     pth_scene** out);
+const ptx_scene_desc* pth_scene_desc(const pth_scene* s);
+void pth_scene_camera(const pth_scene* s, ptx_camera* out);
+void pth_scene_info(const pth_scene* s, pth_info* out);
+void pth_scene_destroy(pth_scene* s);
+
+/* main.cpp:363-374: max over counts, afmhot(count / max) for count > 0, black otherwise.
+ * rgb is width*height*3 floats; returns the maximum. */
+uint32_t pth_heatmap_colour(const uint32_t* counts, uint32_t n_pixels, float* rgb);
+
+/* output.cpp:8-28: clamp, (uint8)(c*255.0), vertical flip, 24-bit BMP.  Returns 0 / -1. */
+int pth_write_bmp(const char* path, const float* rgb, uint32_t width, uint32_t height);
+
+/* Small probes of host arithmetic for the tests (random.hpp:12-29, tiny_obj_loader.h:890-1027,
+ * glm::inverse as used by mesh.cpp:26-29). */
+uint32_t pth_pcg_hash(uint32_t* state);
+float pth_random_float(uint32_t* state);
+int pth_parse_decimal(const char* text, double* out);
+void pth_mat4_inverse(const float m[16], float out[16]);
+void pth_mesh_matrices(const float centroid[3], const float rotation[3], float scale,
+                       const float translation[3], float model[16], float inv_model[16]);
+
+const char* pth_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,546 @@
+#include "loaders.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <array>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+
+namespace pt {
+
+bool g_quiet = false;
+
+namespace {
+
+bool readFile(const std::string& path, std::vector<unsigned char>& out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize(n > 0 ? (size_t)n : 0);
+  size_t got = n > 0 ? fread(out.data(), 1, (size_t)n, f) : 0;
+  fclose(f);
+  return got == out.size();
+}
+
+inline bool isDigit(char c) { return c >= '0' && c <= '9'; }
+
+void finishTriangles(std::vector<Triangle>& tris) {
+  for (Triangle& t : tris) t.centroid = (t.v0 + t.v1 + t.v2) / 3.0f;  // input.cpp:26-28,107-109
+}
+
+}  // namespace
+
+bool fileExists(const std::string& path) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fclose(f);
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// OBJ
+// ---------------------------------------------------------------------------------------------
+
+// Digit-accumulating decimal parser with tinyobjloader's rounding behaviour
+// (tiny_obj_loader.h:890-1027): integer digits as m = m*10 + d, fractional digit k as
+// m += d * 10^-k (table for k < 8, pow() beyond), exponent applied as ldexp(m * 5^e, e).
+bool parseDecimal(const char* s, const char* s_end, double* result) {
+  if (s >= s_end) return false;
+  static const double kNegPow10[] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001};
+  double m = 0.0;
+  int exponent = 0;
+  bool neg = false, expNeg = false, leadingDot = false;
+  const char* c = s;
+  int nread = 0;
+
+  if (*c == '+' || *c == '-') {
+    neg = (*c == '-');
+    c++;
+    if (c != s_end && *c == '.') leadingDot = true;
+  } else if (isDigit(*c)) {
+  } else if (*c == '.') {
+    leadingDot = true;
+  } else {
+    return false;
+  }
+
+  if (!leadingDot) {
+    while (c != s_end && isDigit(*c)) {
+      m *= 10;
+      m += (int)(*c - '0');
+      c++;
+      nread++;
+    }
+    if (nread == 0) return false;
+  }
+  if (c == s_end) goto done;
+
+  if (*c == '.') {
+    c++;
+    nread = 1;
+    while (c != s_end && isDigit(*c)) {
+      m += (int)(*c - '0') * (nread < 8 ? kNegPow10[nread] : std::pow(10.0, -nread));
+      nread++;
+      c++;
+    }
+  } else if (*c == 'e' || *c == 'E') {
+  } else {
+    goto done;
+  }
+  if (c == s_end) goto done;
+
+  if (*c == 'e' || *c == 'E') {
+    c++;
+    if (c != s_end && (*c == '+' || *c == '-')) {
+      expNeg = (*c == '-');
+      c++;
+    } else if (c != s_end && isDigit(*c)) {
+    } else {
+      return false;
+    }
+    nread = 0;
+    while (c != s_end && isDigit(*c)) {
+      if (exponent > 2147483647 / 10) return false;
+      exponent = exponent * 10 + (int)(*c - '0');
+      c++;
+      nread++;
+    }
+    if (expNeg) exponent = -exponent;
+    if (nread == 0) return false;
+  }
+
+done:
+  *result = (neg ? -1 : 1) * (exponent ? std::ldexp(m * std::pow(5.0, exponent), exponent) : m);
+  return true;
+}
+
+namespace {
+
+float parseReal(const char*& p) {
+  p += strspn(p, " \t");
+  const char* end = p + strcspn(p, " \t\r\n");
+  double v = 0.0;
+  parseDecimal(p, end, &v);
+  p = end;
+  return (float)v;
+}
+
+// "v", "v/vt", "v//vn", "v/vt/vn"; 1-based, negative = relative to the running count.
+bool parseCorner(const char*& p, int nv, int nvt, int nvn, int out[3]) {
+  auto fix = [](int idx, int n) { return idx > 0 ? idx - 1 : (idx < 0 ? n + idx : -1); };
+  out[0] = out[1] = out[2] = -1;
+  p += strspn(p, " \t");
+  if (*p == '\0' || *p == '\r' || *p == '\n') return false;
+  out[0] = fix(atoi(p), nv);
+  p += strcspn(p, "/ \t\r\n");
+  if (*p != '/') return true;
+  p++;
+  if (*p == '/') {
+    p++;
+    out[2] = fix(atoi(p), nvn);
+    p += strcspn(p, "/ \t\r\n");
+    return true;
+  }
+  out[1] = fix(atoi(p), nvt);
+  p += strcspn(p, "/ \t\r\n");
+  if (*p != '/') return true;
+  p++;
+  out[2] = fix(atoi(p), nvn);
+  p += strcspn(p, "/ \t\r\n");
+  return true;
+}
+
+}  // namespace
+
+std::vector<Triangle> loadObj(const std::string& path, std::vector<vec3>& normals, std::vector<vec2>& texCoords) {
+  std::ifstream in(path);
+  if (!in) {
+    fprintf(stderr, "OBJ: cannot open %s\n", path.c_str());
+    exit(1);  // input.cpp:43-48
+  }
+  std::vector<float> v, vt, vn;
+  std::vector<vec3> corners;
+  std::string line;
+  while (std::getline(in, line)) {
+    const char* p = line.c_str();
+    p += strspn(p, " \t");
+    if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+      p += 2;
+      for (int k = 0; k < 3; k++) v.push_back(parseReal(p));
+    } else if (p[0] == 'v' && p[1] == 'n' && (p[2] == ' ' || p[2] == '\t')) {
+      p += 3;
+      for (int k = 0; k < 3; k++) vn.push_back(parseReal(p));
+    } else if (p[0] == 'v' && p[1] == 't' && (p[2] == ' ' || p[2] == '\t')) {
+      p += 3;
+      for (int k = 0; k < 2; k++) vt.push_back(parseReal(p));
+    } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+      p += 2;
+      std::vector<std::array<int, 3>> face;
+      int idx[3];
+      while (parseCorner(p, (int)v.size() / 3, (int)vt.size() / 2, (int)vn.size() / 3, idx)) face.push_back({idx[0], idx[1], idx[2]});
+      // Faces with more than three corners are fanned (the bundled scene has triangles only).
+      for (size_t k = 1; k + 1 < face.size(); k++) {
+        const std::array<int, 3>* tri[3] = {&face[0], &face[k], &face[k + 1]};
+        for (auto* c : tri) {
+          int iv = (*c)[0], it = (*c)[1], inn = (*c)[2];
+          corners.push_back(vec3{v[3 * iv], v[3 * iv + 1], v[3 * iv + 2]});
+          if (inn >= 0) normals.push_back(normalize(vec3{vn[3 * inn], vn[3 * inn + 1], vn[3 * inn + 2]}));  // input.cpp:77-82
+          if (it >= 0) texCoords.push_back(vec2{vt[2 * it], (float)(1.0 - (double)vt[2 * it + 1])});           // input.cpp:85-89
+        }
+      }
+    }
+  }
+  std::vector<Triangle> tris;
+  tris.reserve(corners.size() / 3);
+  for (size_t i = 0; i + 2 < corners.size(); i += 3) {
+    Triangle t;
+    t.v0 = corners[i];
+    t.v1 = corners[i + 1];
+    t.v2 = corners[i + 2];
+    tris.push_back(t);
+  }
+  finishTriangles(tris);
+  if (!g_quiet) printf("OBJ triangle count: %zu\n", tris.size());
+  return tris;
+}
+
+// ---------------------------------------------------------------------------------------------
+// STL
+// ---------------------------------------------------------------------------------------------
+
+std::vector<Triangle> loadSTL(const std::string& path) {
+  std::vector<unsigned char> buf;
+  std::vector<Triangle> tris;
+  if (!readFile(path, buf)) return tris;
+  bool binary = false;
+  if (buf.size() >= 84) {
+    uint32_t n;
+    memcpy(&n, buf.data() + 80, 4);
+    binary = (buf.size() == 84 + (size_t)n * 50);
+  }
+  if (binary) {
+    uint32_t n;
+    memcpy(&n, buf.data() + 80, 4);
+    tris.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+      float f[12];
+      memcpy(f, buf.data() + 84 + (size_t)i * 50, 48);
+      tris[i].v0 = vec3{f[3], f[4], f[5]};
+      tris[i].v1 = vec3{f[6], f[7], f[8]};
+      tris[i].v2 = vec3{f[9], f[10], f[11]};
+    }
+  } else {
+    std::string text((const char*)buf.data(), buf.size());
+    size_t pos = 0;
+    std::vector<vec3> vs;
+    while ((pos = text.find("vertex", pos)) != std::string::npos) {
+      pos += 6;
+      char* end = nullptr;
+      const char* p = text.c_str() + pos;
+      float x = strtof(p, &end); p = end;
+      float y = strtof(p, &end); p = end;
+      float z = strtof(p, &end);
+      vs.push_back(vec3{x, y, z});
+    }
+    for (size_t i = 0; i + 2 < vs.size(); i += 3) {
+      Triangle t;
+      t.v0 = vs[i]; t.v1 = vs[i + 1]; t.v2 = vs[i + 2];
+      tris.push_back(t);
+    }
+  }
+  // stl_reader merges vertices with exactly equal coordinates and then drops every triangle that
+  // references one vertex twice (stl_reader.h:498-521); order is otherwise preserved.
+  auto same = [](vec3 a, vec3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; };
+  size_t w = 0;
+  for (size_t i = 0; i < tris.size(); i++) {
+    const Triangle& t = tris[i];
+    if (same(t.v0, t.v1) || same(t.v1, t.v2) || same(t.v0, t.v2)) continue;
+    tris[w++] = t;
+  }
+  tris.resize(w);
+  finishTriangles(tris);
+  if (!g_quiet) printf("STL triangle count: %zu\n", tris.size());
+  return tris;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PNG (8-bit, non-interlaced, colour types 0/2/4/6) -> RGB float / 255
+// ---------------------------------------------------------------------------------------------
+
+namespace {
+uint32_t be32(const unsigned char* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
+
+bool decodePng(const std::vector<unsigned char>& file, uint& w, uint& h, std::vector<unsigned char>& rgb) {
+  static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  if (file.size() < 8 || memcmp(file.data(), sig, 8) != 0) return false;
+  size_t pos = 8;
+  std::vector<unsigned char> idat;
+  int bitDepth = 0, colorType = 0, interlace = 0;
+  w = h = 0;
+  while (pos + 12 <= file.size()) {
+    uint32_t len = be32(&file[pos]);
+    const unsigned char* type = &file[pos + 4];
+    const unsigned char* data = &file[pos + 8];
+    if (pos + 12 + len > file.size()) return false;
+    if (!memcmp(type, "IHDR", 4)) {
+      w = be32(data);
+      h = be32(data + 4);
+      bitDepth = data[8];
+      colorType = data[9];
+      interlace = data[12];
+    } else if (!memcmp(type, "IDAT", 4)) {
+      idat.insert(idat.end(), data, data + len);
+    } else if (!memcmp(type, "IEND", 4)) {
+      break;
+    }
+    pos += 12 + len;
+  }
+  int channels = colorType == 0 ? 1 : colorType == 2 ? 3 : colorType == 4 ? 2 : colorType == 6 ? 4 : 0;
+  if (!w || !h || bitDepth != 8 || channels == 0 || interlace != 0) return false;
+  const size_t stride = (size_t)w * channels;
+  std::vector<unsigned char> raw((stride + 1) * h);
+  uLongf rawLen = raw.size();
+  if (uncompress(raw.data(), &rawLen, idat.data(), idat.size()) != Z_OK || rawLen != raw.size()) return false;
+
+  std::vector<unsigned char> img(stride * h);
+  for (uint y = 0; y < h; y++) {
+    const unsigned char* src = &raw[(stride + 1) * y];
+    unsigned char* cur = &img[stride * y];
+    const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
+    int filter = src[0];
+    src++;
+    for (size_t i = 0; i < stride; i++) {
+      int a = i >= (size_t)channels ? cur[i - channels] : 0;
+      int b = up ? up[i] : 0;
+      int c = (up && i >= (size_t)channels) ? up[i - channels] : 0;
+      int x = src[i];
+      switch (filter) {
+        case 0: break;
+        case 1: x += a; break;
+        case 2: x += b; break;
+        case 3: x += (a + b) >> 1; break;
+        case 4: {
+          int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+          x += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+        } break;
+        default: return false;
+      }
+      cur[i] = (unsigned char)x;
+    }
+  }
+  rgb.resize((size_t)w * h * 3);
+  for (size_t i = 0; i < (size_t)w * h; i++) {
+    const unsigned char* px = &img[i * channels];
+    if (channels >= 3) {
+      rgb[3 * i] = px[0]; rgb[3 * i + 1] = px[1]; rgb[3 * i + 2] = px[2];
+    } else {
+      rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = px[0];
+    }
+  }
+  return true;
+}
+}  // namespace
+
+Image loadImage(const std::string& path) {
+  std::vector<unsigned char> file, rgb;
+  uint w = 0, h = 0;
+  if (!readFile(path, file) || !decodePng(file, w, h, rgb)) {
+    fprintf(stderr, "Failed to load image %s\n", path.c_str());
+    return Image{};
+  }
+  std::vector<vec3> data((size_t)w * h);
+  for (size_t i = 0; i < data.size(); i++)  // input.cpp:142-144
+    data[i] = vec3(rgb[3 * i] / 255.0f, rgb[3 * i + 1] / 255.0f, rgb[3 * i + 2] / 255.0f);
+  return Image{w, h, std::move(data)};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Radiance HDR (RGBE, flat or new-style RLE) -> float RGB
+// ---------------------------------------------------------------------------------------------
+
+Image loadEnvironmentImage(const std::string& path) {
+  std::vector<unsigned char> f;
+  if (!readFile(path, f)) {
+    fprintf(stderr, "Failed to load image %s\n", path.c_str());
+    return Image{};
+  }
+  size_t pos = 0;
+  auto getLine = [&](std::string& s) {
+    s.clear();
+    while (pos < f.size() && f[pos] != '\n') s.push_back((char)f[pos++]);
+    if (pos < f.size()) pos++;
+    return true;
+  };
+  std::string line;
+  getLine(line);
+  if (line != "#?RADIANCE" && line != "#?RGBE") return Image{};
+  bool fmt = false;
+  for (;;) {
+    getLine(line);
+    if (line.empty()) break;
+    if (line == "FORMAT=32-bit_rle_rgbe") fmt = true;
+    if (pos >= f.size()) return Image{};
+  }
+  if (!fmt) return Image{};
+  getLine(line);
+  int H = 0, W = 0;
+  if (sscanf(line.c_str(), "-Y %d +X %d", &H, &W) != 2 || W <= 0 || H <= 0) return Image{};
+
+  std::vector<unsigned char> rgbe((size_t)W * H * 4);
+  bool flat = (W < 8 || W >= 32768);
+  for (int y = 0; y < H && !flat; y++) {
+    if (pos + 4 > f.size()) return Image{};
+    if (f[pos] != 2 || f[pos + 1] != 2 || (f[pos + 2] & 0x80)) {
+      if (y != 0) return Image{};
+      flat = true;
+      break;
+    }
+    if (((int)f[pos + 2] << 8 | f[pos + 3]) != W) return Image{};
+    pos += 4;
+    unsigned char* row = &rgbe[(size_t)y * W * 4];
+    for (int c = 0; c < 4; c++) {
+      int x = 0;
+      while (x < W) {
+        if (pos >= f.size()) return Image{};
+        int count = f[pos++];
+        if (count > 128) {
+          count -= 128;
+          if (pos >= f.size() || x + count > W) return Image{};
+          unsigned char v = f[pos++];
+          for (int k = 0; k < count; k++) row[(x++) * 4 + c] = v;
+        } else {
+          if (count == 0 || x + count > W || pos + count > f.size()) return Image{};
+          for (int k = 0; k < count; k++) row[(x++) * 4 + c] = f[pos++];
+        }
+      }
+    }
+  }
+  if (flat) {
+    if (pos + rgbe.size() > f.size()) return Image{};
+    memcpy(rgbe.data(), &f[pos], rgbe.size());
+  }
+  std::vector<vec3> data((size_t)W * H);
+  for (size_t i = 0; i < data.size(); i++) {
+    const unsigned char* p = &rgbe[4 * i];
+    if (p[3] != 0) {
+      float s = (float)ldexp(1.0f, (int)p[3] - (128 + 8));  // stb_image.h:7130-7155
+      data[i] = vec3(p[0] * s, p[1] * s, p[2] * s);
+    } else {
+      data[i] = vec3(0);
+    }
+  }
+  return Image{(uint)W, (uint)H, std::move(data)};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stand-ins for the two assets missing from the reference checkout
+// ---------------------------------------------------------------------------------------------
+
+namespace {
+// Bust-like closed surface: radius profile over height (shoulders, neck, head) with a fixed
+// multi-octave analytic displacement so the BVH sees scan-like small-scale detail.
+vec3 bustPoint(double u, double v) {  // u in [0,1) around, v in [0,1] bottom -> top
+  const double PI = 3.14159265358979323846;
+  double z = 160.0 * v;
+  double shoulders = 52.0 * std::exp(-std::pow((z - 0.0) / 42.0, 2.0));
+  double neck = 17.0;
+  double head = 33.0 * std::exp(-std::pow((z - 118.0) / 30.0, 2.0));
+  double cap = std::sqrt(std::max(0.0, 1.0 - std::pow(std::max(0.0, (z - 130.0) / 30.0), 2.0)));
+  double r = (neck + shoulders + head) * (z > 130.0 ? cap : 1.0);
+  double a = 2.0 * PI * u;
+  double d = 1.8 * std::sin(3.0 * a + 0.11 * z) * std::sin(0.09 * z + 1.3) + 0.9 * std::sin(7.0 * a - 0.23 * z + 0.7) +
+             0.45 * std::sin(17.0 * a + 0.41 * z) * std::cos(0.37 * z) + 0.22 * std::sin(41.0 * a + 1.7) * std::sin(0.93 * z) +
+             0.10 * std::sin(97.0 * a - 2.1 * z);
+  // squash front-to-back a little and pull the "face" forward
+  double face = 6.0 * std::exp(-std::pow((z - 112.0) / 18.0, 2.0)) * std::max(0.0, std::cos(a));
+  double rr = std::max(0.0, r + (r > 1.0 ? d : 0.0) + face);
+  return vec3((float)(rr * std::cos(a)), (float)(0.92 * rr * std::sin(a)), (float)z);
+}
+}  // namespace
+
+std::vector<Triangle> standInBust(uint target) {
+  // rows x cols quads + bottom and top fans; the remainder up to `target` comes from 1 -> 3 centroid
+  // splits of evenly spaced triangles.
+  uint cols = 632, rows = 399;
+  while (2u * rows * cols + 2u * cols > target && rows > 2) rows--;
+  std::vector<Triangle> tris;
+  tris.reserve(target);
+  auto P = [&](uint i, uint j) { return bustPoint((double)(i % cols) / cols, (double)(j + 1) / (rows + 2)); };
+  vec3 bottom(0.0f, 0.0f, 0.0f), top = bustPoint(0.0, 1.0);
+  top.x = 0.0f; top.y = 0.0f;
+  for (uint i = 0; i < cols; i++) {
+    Triangle t;
+    t.v0 = bottom; t.v1 = P(i + 1, 0); t.v2 = P(i, 0);
+    tris.push_back(t);
+  }
+  for (uint j = 0; j < rows; j++)
+    for (uint i = 0; i < cols; i++) {
+      vec3 a = P(i, j), b = P(i + 1, j), c = P(i + 1, j + 1), d = P(i, j + 1);
+      Triangle t0, t1;
+      t0.v0 = a; t0.v1 = b; t0.v2 = c;
+      t1.v0 = a; t1.v1 = c; t1.v2 = d;
+      tris.push_back(t0);
+      tris.push_back(t1);
+    }
+  for (uint i = 0; i < cols; i++) {
+    Triangle t;
+    t.v0 = top; t.v1 = P(i, rows); t.v2 = P(i + 1, rows);
+    tris.push_back(t);
+  }
+  uint base = (uint)tris.size();
+  uint extra = target > base ? (target - base) / 2u : 0u;
+  for (uint k = 0; k < extra; k++) {
+    uint idx = cols + (uint)(((uint64_t)k * (base - 2u * cols)) / extra);
+    Triangle t = tris[idx];
+    vec3 m = (t.v0 + t.v1 + t.v2) / 3.0f;
+    Triangle a = t, b = t, c = t;
+    a.v2 = m; b.v0 = m; c.v1 = m;
+    tris[idx] = a;
+    tris.push_back(b);
+    tris.push_back(c);
+  }
+  if (tris.size() < target && !tris.empty()) {  // odd remainder: one degenerate-free sliver split
+    Triangle t = tris.back();
+    vec3 m = (t.v0 + t.v1) / 2.0f;
+    Triangle a = t, b = t;
+    a.v1 = m; b.v0 = m;
+    tris.back() = a;
+    tris.push_back(b);
+  }
+  finishTriangles(tris);
+  if (!g_quiet) printf("STL triangle count: %zu (procedural stand-in for models/bust-of-menelaus.stl)\n", tris.size());
+  return tris;
+}
+
+Image standInSky(uint W, uint H) {
+  const double PI = 3.14159265358979323846;
+  std::vector<vec3> data((size_t)W * H);
+  // direction convention of getEnvironment (main.cpp:67-75): u ~ atan2(z,x), v ~ acos(y)
+  const double sunTheta = 1.25, sunPhi = 0.6;  // low evening sun
+  const double sx = std::sin(sunTheta) * std::cos(sunPhi), sy = std::cos(sunTheta), sz = std::sin(sunTheta) * std::sin(sunPhi);
+  for (uint y = 0; y < H; y++) {
+    double theta = PI * (y + 0.5) / H;
+    for (uint x = 0; x < W; x++) {
+      double phi = 2.0 * PI * ((x + 0.5) / W - 0.5);
+      double dx = std::sin(theta) * std::cos(phi), dy = std::cos(theta), dz = std::sin(theta) * std::sin(phi);
+      double up = std::max(0.0, dy);
+      double horizon = std::exp(-6.0 * std::abs(dy));
+      double r = 0.25 + 0.35 * up + 0.9 * horizon, g = 0.32 + 0.45 * up + 0.55 * horizon, b = 0.55 + 0.75 * up + 0.30 * horizon;
+      if (dy < 0) {  // ground
+        double k = std::exp(4.0 * dy);
+        r = 0.10 + 0.5 * k * r; g = 0.09 + 0.5 * k * g; b = 0.08 + 0.5 * k * b;
+      }
+      double c = dx * sx + dy * sy + dz * sz;
+      double lobe = 50.0 * std::pow(std::max(0.0, c), 2000.0) + 2.5 * std::pow(std::max(0.0, c), 40.0);
+      data[(size_t)y * W + x] = vec3((float)(r + lobe), (float)(g + 0.85 * lobe), (float)(b + 0.6 * lobe));
+    }
+  }
+  return Image{W, H, std::move(data)};
+}
+
+}  // namespace pt

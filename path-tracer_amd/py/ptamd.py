@@ -1,0 +1,318 @@
+"""ctypes bindings of the two product libraries, for the Python tests and bench.py.
+
+* libpt_host.so      -- host scene pipeline (include/pt_host.h): presets, BVH build, flatten.
+* libptx_backend.so  -- the HIP backend behind the C ABI (include/ptx_backend.h).
+
+Python is plumbing here, not the product: every render call goes through the C ABI exactly as the
+C++ host program (path-tracer_amd/host/gpu_render.cpp) does.  There is no CPU fallback: if the
+backend library is missing, or no GPU is visible, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.dirname(_HERE)
+REPO_DIR = os.path.dirname(PKG_DIR)
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+GOLDEN_DIR = os.path.join(REPO_DIR, "tests", "golden")
+MODELS_DIR = os.environ.get("PT_MODELS_DIR", os.path.join(GOLDEN_DIR, "models"))
+ENV_PATH = os.environ.get(
+    "PT_ENV_PATH", os.path.join(GOLDEN_DIR, "environment", "evening_road_01_puresky_2k.hdr"))
+
+PTX_NONE = 0xFFFFFFFF
+SEED_REFERENCE_GPU = 0
+SEED_STREAM = 1
+
+
+class BvhNode(C.Structure):
+    _fields_ = [("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3),
+                ("left_first", C.c_uint32), ("count", C.c_uint32)]
+
+
+class Triangle(C.Structure):
+    _fields_ = [("v0", C.c_float * 3), ("v1", C.c_float * 3), ("v2", C.c_float * 3)]
+
+
+class Geometry(C.Structure):
+    _fields_ = [("node_offset", C.c_uint32), ("node_count", C.c_uint32), ("tri_offset", C.c_uint32),
+                ("tri_count", C.c_uint32), ("face_normal_offset", C.c_uint32),
+                ("vtx_normal_offset", C.c_uint32), ("vtx_uv_offset", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Instance(C.Structure):
+    _fields_ = [("inv_model", C.c_float * 16), ("normal_matrix", C.c_float * 16),
+                ("geometry_id", C.c_uint32), ("material_id", C.c_uint32)]
+
+
+class Material(C.Structure):
+    _fields_ = [("albedo", C.c_float * 3), ("metalness", C.c_float), ("roughness", C.c_float),
+                ("emissive", C.c_float * 3), ("f0", C.c_float * 3),
+                ("albedo_texture", C.c_uint32), ("emissive_texture", C.c_uint32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("texel_offset", C.c_uint64)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("tlas_nodes", C.POINTER(BvhNode)), ("tlas_node_count", C.c_uint32),
+        ("instances", C.POINTER(Instance)), ("instance_count", C.c_uint32),
+        ("geometries", C.POINTER(Geometry)), ("geometry_count", C.c_uint32),
+        ("blas_nodes", C.POINTER(BvhNode)), ("blas_node_total", C.c_uint32),
+        ("triangles", C.POINTER(Triangle)), ("triangle_total", C.c_uint32),
+        ("face_normals", C.POINTER(C.c_float)), ("face_normal_total", C.c_uint32),
+        ("vtx_normals", C.POINTER(C.c_float)), ("vtx_normal_total", C.c_uint32),
+        ("vtx_uvs", C.POINTER(C.c_float)), ("vtx_uv_total", C.c_uint32),
+        ("materials", C.POINTER(Material)), ("material_count", C.c_uint32),
+        ("textures", C.POINTER(Texture)), ("texture_count", C.c_uint32),
+        ("texels", C.POINTER(C.c_float)), ("texel_total", C.c_uint64),
+        ("environment", C.POINTER(C.c_float)), ("env_width", C.c_uint32), ("env_height", C.c_uint32),
+    ]
+
+
+class Camera(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("target", C.c_float * 3), ("up", C.c_float * 3),
+                ("fov_deg", C.c_float)]
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32),
+                ("max_bounces", C.c_uint32), ("seed_mode", C.c_uint32), ("part_index", C.c_uint32),
+                ("part_count", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("upload_s", C.c_double), ("render_s", C.c_double), ("rays", C.c_uint64),
+                ("node_steps", C.c_uint64), ("tri_tests", C.c_uint64), ("inst_entries", C.c_uint64),
+                ("hits", C.c_uint64), ("misses", C.c_uint64), ("box_hits", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class HostInfo(C.Structure):
+    _fields_ = [("triangles_per_mesh", C.c_uint32), ("blas_nodes", C.c_uint32), ("tlas_nodes", C.c_uint32),
+                ("instances", C.c_uint32), ("blas_depth", C.c_uint32), ("tlas_depth", C.c_uint32),
+                ("blas_max_leaf", C.c_uint32), ("tlas_max_leaf", C.c_uint32),
+                ("stand_in_geometry", C.c_uint32), ("stand_in_environment", C.c_uint32),
+                ("blas_build_s", C.c_double), ("tlas_build_s", C.c_double)]
+
+
+def make_params(width, height, spp=1, max_bounces=1, seed_mode=SEED_REFERENCE_GPU, part_index=0, part_count=1):
+    return Params(width, height, spp, max_bounces, seed_mode, part_index, part_count, 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# host pipeline
+# ------------------------------------------------------------------------------------------------
+_host = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        path = os.path.join(LIB_DIR, "libpt_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make host` (or __graft_entry__.build()) first")
+        lib = C.CDLL(path)
+        lib.pth_scene_create.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.POINTER(C.c_void_p)]
+        lib.pth_scene_create.restype = C.c_int
+        lib.pth_scene_desc.argtypes = [C.c_void_p]
+        lib.pth_scene_desc.restype = C.POINTER(SceneDesc)
+        lib.pth_scene_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
+        lib.pth_scene_info.argtypes = [C.c_void_p, C.POINTER(HostInfo)]
+        lib.pth_scene_destroy.argtypes = [C.c_void_p]
+        lib.pth_heatmap_colour.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.pth_heatmap_colour.restype = C.c_uint32
+        lib.pth_write_bmp.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.pth_write_bmp.restype = C.c_int
+        lib.pth_pcg_hash.argtypes = [C.POINTER(C.c_uint32)]
+        lib.pth_pcg_hash.restype = C.c_uint32
+        lib.pth_random_float.argtypes = [C.POINTER(C.c_uint32)]
+        lib.pth_random_float.restype = C.c_float
+        lib.pth_parse_decimal.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
+        lib.pth_parse_decimal.restype = C.c_int
+        lib.pth_mat4_inverse.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pth_mesh_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pth_last_error.restype = C.c_char_p
+        _host = lib
+    return _host
+
+
+class HostScene:
+    """A preset scene built by the host pipeline (getScene + completeScene + flatten)."""
+
+    def __init__(self, preset, scatter_instances=0, sky=(0, 0), models_dir=None, env_path=None):
+        lib = host_lib()
+        self._h = C.c_void_p()
+        rc = lib.pth_scene_create(preset, (models_dir or MODELS_DIR).encode(), (env_path or ENV_PATH).encode(),
+                                  scatter_instances, sky[0], sky[1], C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(lib.pth_last_error().decode())
+        self.preset = preset
+        self.desc_ptr = lib.pth_scene_desc(self._h)
+        self.desc = self.desc_ptr.contents
+        self.camera = Camera()
+        lib.pth_scene_camera(self._h, C.byref(self.camera))
+        self.info = HostInfo()
+        lib.pth_scene_info(self._h, C.byref(self.info))
+
+    def close(self):
+        if self._h:
+            host_lib().pth_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # numpy views of the flattened arrays (no copies)
+    def _view(self, ptr, count, dtype, shape_tail=()):
+        if count == 0 or not ptr:
+            return np.zeros((0,) + shape_tail, dtype=dtype)
+        n = int(np.prod(shape_tail)) if shape_tail else 1
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * n * np.dtype(dtype).itemsize,))
+        return arr.view(dtype).reshape((count,) + shape_tail)
+
+    @property
+    def tlas_nodes(self):
+        return self._view(self.desc.tlas_nodes, self.desc.tlas_node_count, np.uint32, (8,))
+
+    @property
+    def blas_nodes(self):
+        return self._view(self.desc.blas_nodes, self.desc.blas_node_total, np.uint32, (8,))
+
+    @property
+    def triangles(self):
+        return self._view(self.desc.triangles, self.desc.triangle_total, np.float32, (9,))
+
+    @property
+    def instances(self):
+        return self._view(self.desc.instances, self.desc.instance_count, np.float32, (34,))
+
+
+def heatmap_colour(counts):
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    rgb = np.empty(counts.shape + (3,), dtype=np.float32)
+    mx = host_lib().pth_heatmap_colour(counts.ctypes.data, counts.size, rgb.ctypes.data)
+    return rgb, mx
+
+
+def write_bmp(path, rgb):
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w = rgb.shape[:2]
+    if host_lib().pth_write_bmp(path.encode(), rgb.ctypes.data, w, h) != 0:
+        raise RuntimeError(f"cannot write {path}")
+
+
+# ------------------------------------------------------------------------------------------------
+# HIP backend
+# ------------------------------------------------------------------------------------------------
+_backend = None
+
+BACKEND_SYMBOLS = [
+    "ptx_device_count", "ptx_create", "ptx_render_counts", "ptx_render", "ptx_accumulate_device",
+    "ptx_resolve_device", "ptx_counts_device", "ptx_measure", "ptx_last_kernel_seconds", "ptx_destroy",
+    "ptx_last_error", "ptx_version",
+]
+
+
+def backend_lib():
+    global _backend
+    if _backend is None:
+        path = os.path.join(LIB_DIR, "libptx_backend.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make backend` (or __graft_entry__.build()); "
+                               "there is no CPU fallback for the render path")
+        lib = C.CDLL(path)
+        vp = C.c_void_p
+        lib.ptx_device_count.argtypes = [C.POINTER(C.c_int)]
+        lib.ptx_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(vp)]
+        lib.ptx_render_counts.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.POINTER(Stats)]
+        lib.ptx_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.POINTER(Stats)]
+        lib.ptx_accumulate_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, vp]
+        lib.ptx_resolve_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp]
+        lib.ptx_counts_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, vp]
+        lib.ptx_measure.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), C.c_int, C.POINTER(Stats)]
+        lib.ptx_last_kernel_seconds.argtypes = [vp, C.POINTER(C.c_double)]
+        lib.ptx_destroy.argtypes = [vp]
+        lib.ptx_destroy.restype = None
+        lib.ptx_last_error.restype = C.c_char_p
+        lib.ptx_version.restype = C.c_char_p
+        for name in BACKEND_SYMBOLS:
+            getattr(lib, name)
+        _backend = lib
+    return _backend
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise BackendError(f"{what} failed ({rc}): {backend_lib().ptx_last_error().decode()}")
+
+
+class DeviceScene:
+    """ptx_create / ptx_destroy around a flattened scene."""
+
+    def __init__(self, desc_ptr, device=0):
+        lib = backend_lib()
+        self._h = C.c_void_p()
+        _check(lib.ptx_create(desc_ptr, device, C.byref(self._h)), "ptx_create")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            backend_lib().ptx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_counts(self, camera, params):
+        out = np.empty((params.height, params.width), dtype=np.uint32)
+        st = Stats()
+        _check(backend_lib().ptx_render_counts(self._h, C.byref(camera), C.byref(params), out.ctypes.data, C.byref(st)),
+               "ptx_render_counts")
+        return out, st
+
+    def render(self, camera, params):
+        out = np.empty((params.height, params.width, 3), dtype=np.float32)
+        st = Stats()
+        _check(backend_lib().ptx_render(self._h, C.byref(camera), C.byref(params), out.ctypes.data, C.byref(st)),
+               "ptx_render")
+        return out, st
+
+    def accumulate_device(self, camera, params, d_accum_ptr, stream=None):
+        _check(backend_lib().ptx_accumulate_device(self._h, C.byref(camera), C.byref(params), d_accum_ptr, stream),
+               "ptx_accumulate_device")
+
+    def resolve_device(self, d_accum_ptr, width, height, d_out_ptr, stream=None):
+        _check(backend_lib().ptx_resolve_device(self._h, d_accum_ptr, width, height, d_out_ptr, stream),
+               "ptx_resolve_device")
+
+    def counts_device(self, camera, params, d_counts_ptr, stream=None):
+        _check(backend_lib().ptx_counts_device(self._h, C.byref(camera), C.byref(params), d_counts_ptr, stream),
+               "ptx_counts_device")
+
+    def measure(self, camera, params, heatmap=False):
+        st = Stats()
+        _check(backend_lib().ptx_measure(self._h, C.byref(camera), C.byref(params), int(heatmap), C.byref(st)),
+               "ptx_measure")
+        return st
+
+    def last_kernel_seconds(self):
+        s = C.c_double()
+        _check(backend_lib().ptx_last_kernel_seconds(self._h, C.byref(s)), "ptx_last_kernel_seconds")
+        return s.value

@@ -1,0 +1,84 @@
+"""ctypes binding of the CPU oracle (oracle/libpt_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "path-tracer_amd", "py"))
+import ptamd  # noqa: E402
+
+SEED_REFERENCE_CPU = 100
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(REPO, "oracle", "libpt_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make oracle`")
+        L = C.CDLL(path)
+        vp, u32, f32 = C.c_void_p, C.c_uint32, C.c_float
+        P = C.POINTER
+        L.oracle_render_counts.argtypes = [P(ptamd.SceneDesc), P(ptamd.Camera), P(ptamd.Params), C.c_int, vp, P(ptamd.Stats)]
+        L.oracle_render.argtypes = [P(ptamd.SceneDesc), P(ptamd.Camera), P(ptamd.Params), u32, C.c_int, vp, P(ptamd.Stats)]
+        L.oracle_accumulate.argtypes = [P(ptamd.SceneDesc), P(ptamd.Camera), P(ptamd.Params), u32, C.c_int, vp, P(ptamd.Stats)]
+        L.oracle_resolve.argtypes = [vp, u32, vp]
+        L.oracle_slab.argtypes = [vp, vp, f32, vp, vp]
+        L.oracle_slab.restype = f32
+        L.oracle_triangle.argtypes = [vp, vp, vp, vp]
+        L.oracle_triangle.restype = f32
+        L.oracle_pcg_hash.argtypes = [P(u32)]
+        L.oracle_pcg_hash.restype = u32
+        L.oracle_random_float.argtypes = [P(u32)]
+        L.oracle_random_float.restype = f32
+        L.oracle_random_vec2.argtypes = [P(u32), vp]
+        L.oracle_primary_ray.argtypes = [P(ptamd.Camera), u32, u32, f32, f32, vp]
+        L.oracle_sample_cosine.argtypes = [vp, vp, vp]
+        L.oracle_sample_ggx.argtypes = [vp, vp, f32, vp]
+        L.oracle_environment_index.argtypes = [P(ptamd.SceneDesc), vp]
+        L.oracle_environment_index.restype = u32
+        L.oracle_tonemap.argtypes = [vp, f32, vp]
+        L.oracle_trace.argtypes = [P(ptamd.SceneDesc), vp, vp, vp, vp, vp, vp]
+        L.oracle_trace.restype = u32
+        _lib = L
+    return _lib
+
+
+def render_counts(scene, params, threads=None):
+    out = np.empty((params.height, params.width), dtype=np.uint32)
+    st = ptamd.Stats()
+    rc = lib().oracle_render_counts(scene.desc_ptr, C.byref(scene.camera), C.byref(params),
+                                    threads or (os.cpu_count() or 1), out.ctypes.data, C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"oracle_render_counts failed ({rc})")
+    return out, st
+
+
+def render(scene, params, seed_mode=0, threads=None):
+    out = np.empty((params.height, params.width, 3), dtype=np.float32)
+    st = ptamd.Stats()
+    rc = lib().oracle_render(scene.desc_ptr, C.byref(scene.camera), C.byref(params), seed_mode,
+                             threads or (os.cpu_count() or 1), out.ctypes.data, C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"oracle_render failed ({rc})")
+    return out, st
+
+
+def accumulate(scene, params, seed_mode=0, threads=None):
+    out = np.empty((params.height, params.width, 4), dtype=np.float32)
+    st = ptamd.Stats()
+    rc = lib().oracle_accumulate(scene.desc_ptr, C.byref(scene.camera), C.byref(params), seed_mode,
+                                 threads or (os.cpu_count() or 1), out.ctypes.data, C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"oracle_accumulate failed ({rc})")
+    return out, st
+
+
+def resolve(accum):
+    accum = np.ascontiguousarray(accum, dtype=np.float32)
+    out = np.empty(accum.shape[:-1] + (3,), dtype=np.float32)
+    lib().oracle_resolve(accum.ctypes.data, accum.size // 4, out.ctypes.data)
+    return out
