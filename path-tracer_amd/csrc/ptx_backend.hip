@@ -1,0 +1,526 @@
+// C ABI of the gfx950 path-tracing backend (include/ptx_backend.h): scene validation and re-layout,
+// one-arena upload, kernel launches, timing.  Replaces renderGPU's body (gpuRender.cu:172-311).
+#include "../../include/ptx_backend.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device_scene.hpp"
+#include "kernels.hpp"
+
+using namespace ptx;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+  g_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      char buf_[512];                                                                               \
+      snprintf(buf_, sizeof(buf_), "HIP error at %s:%d: %s (%s)", __FILE__, __LINE__,                \
+               hipGetErrorString(e_), #expr);                                                       \
+      return fail(PTX_EHIP, buf_);                                                                  \
+    }                                                                                               \
+  } while (0)
+
+struct TreeInfo {
+  uint32_t rootRef = 0;
+  uint32_t depth = 0;
+};
+
+// Converts one reference-layout tree (32-byte nodes, children adjacent at left_first, left_first+1)
+// into NodePair records appended to `pairs`.  primBase is added to leaf primitive indices.
+int convertTree(const ptx_bvh_node* nodes, uint32_t n, uint32_t primBase, uint32_t primCount, const char* what,
+                std::vector<NodePair>& pairs, TreeInfo& info) {
+  if (n == 0 || (n & 1u) == 0u) return fail(PTX_EINVAL, std::string(what) + ": node count must be odd and > 0");
+  const uint32_t pairBase = (uint32_t)pairs.size();
+  const uint32_t nPairs = (n - 1u) / 2u;
+  if ((uint64_t)pairBase + nPairs >= kLeafFlag) return fail(PTX_ELIMIT, "too many BVH nodes");
+  pairs.resize((size_t)pairBase + nPairs);
+
+  auto makeRef = [&](const ptx_bvh_node& nd, uint32_t& ref) -> int {
+    if (nd.count > 0) {
+      if (nd.count > kMaxLeafPrims) return fail(PTX_ELIMIT, std::string(what) + ": a leaf holds more than 128 primitives");
+      if ((uint64_t)nd.left_first + nd.count > primCount) return fail(PTX_EINVAL, std::string(what) + ": leaf range outside the primitive array");
+      if ((uint64_t)primBase + nd.left_first + nd.count > kMaxPrimIndex) return fail(PTX_ELIMIT, "primitive index exceeds 24 bits");
+      ref = makeLeafRef(primBase + nd.left_first, nd.count);
+    } else {
+      if ((nd.left_first & 1u) == 0u || (uint64_t)nd.left_first + 1u >= n)
+        return fail(PTX_EINVAL, std::string(what) + ": child index not of the form 2k+1 / out of range");
+      ref = pairBase + (nd.left_first - 1u) / 2u;
+    }
+    return PTX_OK;
+  };
+
+  int rc = makeRef(nodes[0], info.rootRef);
+  if (rc) return rc;
+
+  // depth-first walk: fills pairs, measures depth, rejects cycles (each node may be visited once)
+  std::vector<uint8_t> seen(n, 0);
+  std::vector<std::pair<uint32_t, uint32_t>> todo;
+  todo.emplace_back(0u, 0u);
+  seen[0] = 1;
+  info.depth = 0;
+  while (!todo.empty()) {
+    auto [i, depth] = todo.back();
+    todo.pop_back();
+    if (depth > info.depth) info.depth = depth;
+    const ptx_bvh_node& nd = nodes[i];
+    if (nd.count > 0) continue;
+    const uint32_t l = nd.left_first, r = l + 1u;
+    if ((l & 1u) == 0u || r >= n || seen[l] || seen[r]) return fail(PTX_EINVAL, std::string(what) + ": malformed node links");
+    seen[l] = seen[r] = 1;
+    NodePair& p = pairs[(size_t)pairBase + (l - 1u) / 2u];
+    uint32_t lref, rref;
+    if ((rc = makeRef(nodes[l], lref))) return rc;
+    if ((rc = makeRef(nodes[r], rref))) return rc;
+    p.lmin = make_float4(nodes[l].aabb_min[0], nodes[l].aabb_min[1], nodes[l].aabb_min[2], __builtin_bit_cast(float, lref));
+    p.lmax = make_float4(nodes[l].aabb_max[0], nodes[l].aabb_max[1], nodes[l].aabb_max[2], 0.0f);
+    p.rmin = make_float4(nodes[r].aabb_min[0], nodes[r].aabb_min[1], nodes[r].aabb_min[2], __builtin_bit_cast(float, rref));
+    p.rmax = make_float4(nodes[r].aabb_max[0], nodes[r].aabb_max[1], nodes[r].aabb_max[2], 0.0f);
+    todo.emplace_back(r, depth + 1u);
+    todo.emplace_back(l, depth + 1u);
+  }
+  return PTX_OK;
+}
+
+template <typename T>
+size_t arenaReserve(size_t& cursor, size_t count) {
+  cursor = (cursor + 255u) & ~size_t(255);
+  size_t off = cursor;
+  cursor += count * sizeof(T);
+  return off;
+}
+
+double nowSeconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct ptx_scene {
+  int device = 0;
+  void* arena = nullptr;
+  size_t arenaBytes = 0;
+  DeviceScene dev{};
+  uint32_t tlasDepth = 0, blasDepth = 0;
+  double uploadSeconds = 0;
+  // per-handle scratch, grown on demand
+  void* outBuf = nullptr;
+  size_t outBytes = 0;
+  DeviceStats* dStats = nullptr;
+  hipEvent_t evStart = nullptr, evStop = nullptr;
+  hipStream_t lastStream = nullptr;
+  bool timed = false;
+};
+
+namespace {
+
+int ensureOut(ptx_scene* s, size_t bytes) {
+  if (s->outBytes >= bytes) return PTX_OK;
+  if (s->outBuf) HIP_TRY(hipFree(s->outBuf));
+  s->outBuf = nullptr;
+  s->outBytes = 0;
+  HIP_TRY(hipMalloc(&s->outBuf, bytes));
+  s->outBytes = bytes;
+  return PTX_OK;
+}
+
+int makeFrame(const ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, bool heatmap, FrameConstants& fc) {
+  if (!s || !cam || !prm) return fail(PTX_EINVAL, "null argument");
+  if (prm->width == 0 || prm->height == 0) return fail(PTX_EINVAL, "empty image");
+  if ((uint64_t)prm->width * prm->height > (1ull << 24))
+    return fail(PTX_ELIMIT, "more than 2^24 pixels: pixel coordinates would no longer be exact in float (main.cpp:199)");
+  if (!heatmap && prm->spp == 0) return fail(PTX_EINVAL, "spp must be > 0");
+  if (prm->part_count > 1u && prm->part_index >= prm->part_count) return fail(PTX_EINVAL, "part_index >= part_count");
+  using pt::vec3;
+  memset(&fc, 0, sizeof(fc));
+  const vec3 pos(cam->position[0], cam->position[1], cam->position[2]);
+  const vec3 at(cam->target[0], cam->target[1], cam->target[2]);
+  const vec3 up(cam->up[0], cam->up[1], cam->up[2]);
+  // camera.hpp:14-20
+  const vec3 zaxis = pt::normalize(at - pos);
+  const vec3 xaxis = pt::normalize(pt::cross(zaxis, up));
+  const vec3 yaxis = pt::cross(xaxis, zaxis);
+  const vec3 nz = -zaxis;
+  fc.camPos[0] = pos.x; fc.camPos[1] = pos.y; fc.camPos[2] = pos.z;
+  fc.viewC0[0] = xaxis.x; fc.viewC0[1] = xaxis.y; fc.viewC0[2] = xaxis.z;
+  fc.viewC1[0] = yaxis.x; fc.viewC1[1] = yaxis.y; fc.viewC1[2] = yaxis.z;
+  fc.viewC2[0] = nz.x; fc.viewC2[1] = nz.y; fc.viewC2[2] = nz.z;
+  // camera.hpp:8-12
+  const float resx = (float)prm->width, resy = (float)prm->height;
+  fc.halfResX = 0.5f * resx;
+  fc.halfResY = 0.5f * resy;
+  const float z = (0.5f * resy) / tanf(0.5f * pt::radians(cam->fov_deg));
+  fc.negZ = -z;
+  // gpuFunctions.hpp:51-52 with angle = (float)(-M_PI) (gpuRender.cu:16)
+  const float angle = (float)(-M_PI);
+  fc.envQy = (float)sin(angle / 2.0);
+  fc.envQw = (float)cos(angle / 2.0);
+  fc.width = prm->width;
+  fc.height = prm->height;
+  fc.spp = heatmap ? 1u : prm->spp;
+  fc.maxBounces = heatmap ? 1u : prm->max_bounces;
+  fc.seedBase = 1023u;
+  if (prm->seed_mode == PTX_SEED_STREAM) fc.seedBase += prm->part_index * 0x9E3779B9u;
+  else if (prm->seed_mode != PTX_SEED_REFERENCE_GPU) return fail(PTX_EINVAL, "unknown seed_mode");
+  fc.partIndex = prm->part_index;
+  fc.partCount = prm->part_count;
+  fc.tilesX = (prm->width + 7u) / 8u;
+  fc.tilesY = (prm->height + 7u) / 8u;
+  return PTX_OK;
+}
+
+int launchCounts(ptx_scene* s, const FrameConstants& fc, uint32_t* dOut, hipStream_t stream, bool stats) {
+  const uint32_t nTiles = fc.tilesX * fc.tilesY;
+  HIP_TRY(hipEventRecord(s->evStart, stream));
+  if (stats) countsKernel<true><<<dim3(nTiles), dim3(64), 0, stream>>>(s->dev, fc, dOut, s->dStats);
+  else countsKernel<false><<<dim3(nTiles), dim3(64), 0, stream>>>(s->dev, fc, dOut, s->dStats);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->evStop, stream));
+  s->lastStream = stream;
+  s->timed = true;
+  return PTX_OK;
+}
+
+int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool resolve, hipStream_t stream, bool stats) {
+  const uint32_t nTiles = fc.tilesX * fc.tilesY;
+  HIP_TRY(hipEventRecord(s->evStart, stream));
+  const dim3 grid(nTiles), block(64);
+  if (stats) {
+    if (resolve) radianceKernel<true, true><<<grid, block, 0, stream>>>(s->dev, fc, dOut, s->dStats);
+    else radianceKernel<true, false><<<grid, block, 0, stream>>>(s->dev, fc, dOut, s->dStats);
+  } else {
+    if (resolve) radianceKernel<false, true><<<grid, block, 0, stream>>>(s->dev, fc, dOut, s->dStats);
+    else radianceKernel<false, false><<<grid, block, 0, stream>>>(s->dev, fc, dOut, s->dStats);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->evStop, stream));
+  s->lastStream = stream;
+  s->timed = true;
+  return PTX_OK;
+}
+
+int kernelSeconds(ptx_scene* s, double* out) {
+  if (!s->timed) return fail(PTX_EINVAL, "no launch has been made through this handle");
+  HIP_TRY(hipEventSynchronize(s->evStop));
+  float ms = 0.0f;
+  HIP_TRY(hipEventElapsedTime(&ms, s->evStart, s->evStop));
+  *out = (double)ms * 1e-3;
+  return PTX_OK;
+}
+
+int readStats(ptx_scene* s, ptx_stats* st) {
+  DeviceStats h;
+  HIP_TRY(hipMemcpy(&h, s->dStats, sizeof(h), hipMemcpyDeviceToHost));
+  st->rays = h.rays; st->node_steps = h.nodeSteps; st->tri_tests = h.triTests; st->inst_entries = h.instEntries;
+  st->hits = h.hits; st->misses = h.misses; st->box_hits = h.boxHits;
+  return PTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ptx_last_error(void) { return g_error.c_str(); }
+
+const char* ptx_version(void) {
+  static std::string v;
+  if (v.empty()) {
+    int rt = 0;
+    (void)hipRuntimeGetVersion(&rt);
+    v = "ptx_backend 0.1 gfx950 HIP " + std::to_string(rt);
+  }
+  return v.c_str();
+}
+
+int ptx_device_count(int* count) {
+  if (!count) return fail(PTX_EINVAL, "null argument");
+  *count = 0;
+  HIP_TRY(hipGetDeviceCount(count));
+  return PTX_OK;
+}
+
+int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
+  if (!d || !out) return fail(PTX_EINVAL, "null argument");
+  *out = nullptr;
+  if (!d->tlas_nodes || !d->instances || !d->geometries || !d->blas_nodes || !d->triangles || !d->face_normals ||
+      !d->materials || !d->environment)
+    return fail(PTX_EINVAL, "scene description has a null required array");
+  if (d->instance_count == 0 || d->geometry_count == 0 || d->material_count == 0 || d->env_width == 0 || d->env_height == 0)
+    return fail(PTX_EINVAL, "scene description has an empty required array");
+  if ((uint64_t)d->env_width * d->env_height >= (1ull << 32)) return fail(PTX_ELIMIT, "environment map too large");
+  const double t0 = nowSeconds();
+
+  // ---- host re-layout ----
+  std::vector<NodePair> pairs;
+  TreeInfo tlas;
+  int rc = convertTree(d->tlas_nodes, d->tlas_node_count, 0u, d->instance_count, "TLAS", pairs, tlas);
+  if (rc) return rc;
+
+  std::vector<TreeInfo> blas(d->geometry_count);
+  std::vector<GeomShade> geomShade(d->geometry_count);
+  uint32_t blasDepth = 0;
+  for (uint32_t g = 0; g < d->geometry_count; g++) {
+    const ptx_geometry& G = d->geometries[g];
+    if ((uint64_t)G.node_offset + G.node_count > d->blas_node_total || (uint64_t)G.tri_offset + G.tri_count > d->triangle_total)
+      return fail(PTX_EINVAL, "geometry ranges outside the pooled arrays");
+    if ((uint64_t)G.face_normal_offset + G.tri_count > d->face_normal_total) return fail(PTX_EINVAL, "face normal range outside the array");
+    if (G.vtx_normal_offset != PTX_NONE && (!d->vtx_normals || (uint64_t)G.vtx_normal_offset + 3ull * G.tri_count > d->vtx_normal_total))
+      return fail(PTX_EINVAL, "vertex normal range outside the array");
+    if (G.vtx_uv_offset != PTX_NONE && (!d->vtx_uvs || (uint64_t)G.vtx_uv_offset + 3ull * G.tri_count > d->vtx_uv_total))
+      return fail(PTX_EINVAL, "uv range outside the array");
+    rc = convertTree(d->blas_nodes + G.node_offset, G.node_count, G.tri_offset, G.tri_count, "BLAS", pairs, blas[g]);
+    if (rc) return rc;
+    if (blas[g].depth > blasDepth) blasDepth = blas[g].depth;
+    geomShade[g].triBase = G.tri_offset;
+    geomShade[g].faceNormalBase = G.face_normal_offset;
+    geomShade[g].vtxNormalBase = G.vtx_normal_offset;
+    geomShade[g].vtxUvBase = G.vtx_uv_offset;
+  }
+  if (tlas.depth + blasDepth + 2u > kStackEntries) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "BVH too deep for the traversal stack: TLAS depth %u + BLAS depth %u + 2 > %u", tlas.depth,
+             blasDepth, kStackEntries);
+    return fail(PTX_ELIMIT, buf);
+  }
+
+  std::vector<TriRec> tris(d->triangle_total);
+  for (uint32_t i = 0; i < d->triangle_total; i++) {
+    const ptx_triangle& t = d->triangles[i];
+    // edge1 = v1 - v0, edge2 = v2 - v0: the subtractions of intersection.hpp:11-12, done once
+    tris[i].v0 = make_float4(t.v0[0], t.v0[1], t.v0[2], 0.0f);
+    tris[i].e1 = make_float4(t.v1[0] - t.v0[0], t.v1[1] - t.v0[1], t.v1[2] - t.v0[2], 0.0f);
+    tris[i].e2 = make_float4(t.v2[0] - t.v0[0], t.v2[1] - t.v0[1], t.v2[2] - t.v0[2], 0.0f);
+  }
+
+  std::vector<InstXform> ix(d->instance_count);
+  std::vector<InstShade> is(d->instance_count);
+  for (uint32_t i = 0; i < d->instance_count; i++) {
+    const ptx_instance& I = d->instances[i];
+    if (I.geometry_id >= d->geometry_count || I.material_id >= d->material_count) return fail(PTX_EINVAL, "instance refers to a missing geometry/material");
+    const float* m = I.inv_model;
+    ix[i].row0 = make_float4(m[0], m[4], m[8], m[12]);
+    ix[i].row1 = make_float4(m[1], m[5], m[9], m[13]);
+    ix[i].row2 = make_float4(m[2], m[6], m[10], m[14]);
+    ix[i].rootRef = blas[I.geometry_id].rootRef;
+    ix[i].pad[0] = ix[i].pad[1] = ix[i].pad[2] = 0;
+    const float* nm = I.normal_matrix;
+    is[i].row0 = make_float4(nm[0], nm[4], nm[8], nm[12]);
+    is[i].row1 = make_float4(nm[1], nm[5], nm[9], nm[13]);
+    is[i].row2 = make_float4(nm[2], nm[6], nm[10], nm[14]);
+    is[i].geometryId = I.geometry_id;
+    is[i].materialId = I.material_id;
+    is[i].pad[0] = is[i].pad[1] = 0;
+  }
+
+  std::vector<MaterialRec> mats(d->material_count);
+  for (uint32_t i = 0; i < d->material_count; i++) {
+    const ptx_material& M = d->materials[i];
+    if ((M.albedo_texture != PTX_NONE && M.albedo_texture >= d->texture_count) ||
+        (M.emissive_texture != PTX_NONE && M.emissive_texture >= d->texture_count))
+      return fail(PTX_EINVAL, "material refers to a missing texture");
+    mats[i].albedoMetal = make_float4(M.albedo[0], M.albedo[1], M.albedo[2], M.metalness);
+    mats[i].emissiveRough = make_float4(M.emissive[0], M.emissive[1], M.emissive[2], M.roughness);
+    mats[i].f0 = make_float4(M.f0[0], M.f0[1], M.f0[2], 0.0f);
+    mats[i].albedoTex = M.albedo_texture;
+    mats[i].emissiveTex = M.emissive_texture;
+    mats[i].pad[0] = mats[i].pad[1] = 0;
+  }
+  std::vector<TextureRec> texs(d->texture_count);
+  for (uint32_t i = 0; i < d->texture_count; i++) {
+    const ptx_texture& T = d->textures[i];
+    if (T.texel_offset + (uint64_t)T.width * T.height > d->texel_total || d->texel_total >= (1ull << 32))
+      return fail(PTX_EINVAL, "texture range outside the texel array");
+    texs[i].width = T.width; texs[i].height = T.height; texs[i].texelBase = (uint32_t)T.texel_offset; texs[i].pad = 0;
+  }
+  auto pad4 = [](const float* src, size_t n) {
+    std::vector<float4> v(n);
+    for (size_t i = 0; i < n; i++) v[i] = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], 0.0f);
+    return v;
+  };
+  std::vector<float4> faceN = pad4(d->face_normals, d->face_normal_total);
+  std::vector<float4> vtxN = d->vtx_normals ? pad4(d->vtx_normals, d->vtx_normal_total) : std::vector<float4>();
+  std::vector<float4> texels = d->texels ? pad4(d->texels, d->texel_total) : std::vector<float4>();
+  std::vector<float4> env = pad4(d->environment, (size_t)d->env_width * d->env_height);
+
+  // ---- one arena, one allocation ----
+  size_t cur = 0;
+  const size_t oPairs = arenaReserve<NodePair>(cur, pairs.size() ? pairs.size() : 1);
+  const size_t oTris = arenaReserve<TriRec>(cur, tris.size());
+  const size_t oIx = arenaReserve<InstXform>(cur, ix.size());
+  const size_t oIs = arenaReserve<InstShade>(cur, is.size());
+  const size_t oGs = arenaReserve<GeomShade>(cur, geomShade.size());
+  const size_t oFn = arenaReserve<float4>(cur, faceN.size());
+  const size_t oVn = arenaReserve<float4>(cur, vtxN.size() ? vtxN.size() : 1);
+  const size_t oUv = arenaReserve<float2>(cur, d->vtx_uv_total ? d->vtx_uv_total : 1);
+  const size_t oMat = arenaReserve<MaterialRec>(cur, mats.size());
+  const size_t oTex = arenaReserve<TextureRec>(cur, texs.size() ? texs.size() : 1);
+  const size_t oTexels = arenaReserve<float4>(cur, texels.size() ? texels.size() : 1);
+  const size_t oEnv = arenaReserve<float4>(cur, env.size());
+  cur = (cur + 255u) & ~size_t(255);
+
+  HIP_TRY(hipSetDevice(device));
+  ptx_scene* s = new ptx_scene();
+  s->device = device;
+  s->arenaBytes = cur;
+  hipError_t e = hipMalloc(&s->arena, cur);
+  if (e != hipSuccess) {
+    delete s;
+    return fail(PTX_EHIP, std::string("hipMalloc of the scene arena failed: ") + hipGetErrorString(e));
+  }
+  char* base = (char*)s->arena;
+  auto up = [&](size_t off, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpy(base + off, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+  };
+  hipError_t errs[] = {
+      up(oPairs, pairs.data(), pairs.size() * sizeof(NodePair)), up(oTris, tris.data(), tris.size() * sizeof(TriRec)),
+      up(oIx, ix.data(), ix.size() * sizeof(InstXform)),         up(oIs, is.data(), is.size() * sizeof(InstShade)),
+      up(oGs, geomShade.data(), geomShade.size() * sizeof(GeomShade)), up(oFn, faceN.data(), faceN.size() * sizeof(float4)),
+      up(oVn, vtxN.data(), vtxN.size() * sizeof(float4)),        up(oUv, d->vtx_uvs, (size_t)d->vtx_uv_total * sizeof(float2)),
+      up(oMat, mats.data(), mats.size() * sizeof(MaterialRec)),  up(oTex, texs.data(), texs.size() * sizeof(TextureRec)),
+      up(oTexels, texels.data(), texels.size() * sizeof(float4)), up(oEnv, env.data(), env.size() * sizeof(float4)),
+      hipMalloc((void**)&s->dStats, sizeof(DeviceStats)),        hipEventCreate(&s->evStart), hipEventCreate(&s->evStop)};
+  for (hipError_t er : errs)
+    if (er != hipSuccess) {
+      std::string msg = std::string("scene upload failed: ") + hipGetErrorString(er);
+      ptx_destroy(s);
+      return fail(PTX_EHIP, msg);
+    }
+  DeviceScene& D = s->dev;
+  D.pairs = (const NodePair*)(base + oPairs);
+  D.tris = (const TriRec*)(base + oTris);
+  D.instXform = (const InstXform*)(base + oIx);
+  D.instShade = (const InstShade*)(base + oIs);
+  D.geomShade = (const GeomShade*)(base + oGs);
+  D.faceNormals = (const float4*)(base + oFn);
+  D.vtxNormals = (const float4*)(base + oVn);
+  D.vtxUvs = (const float2*)(base + oUv);
+  D.materials = (const MaterialRec*)(base + oMat);
+  D.textures = (const TextureRec*)(base + oTex);
+  D.texels = (const float4*)(base + oTexels);
+  D.environment = (const float4*)(base + oEnv);
+  D.tlasRootRef = tlas.rootRef;
+  D.envWidth = d->env_width;
+  D.envHeight = d->env_height;
+  s->tlasDepth = tlas.depth;
+  s->blasDepth = blasDepth;
+  s->uploadSeconds = nowSeconds() - t0;
+  *out = s;
+  return PTX_OK;
+}
+
+void ptx_destroy(ptx_scene* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->arena) (void)hipFree(s->arena);
+  if (s->outBuf) (void)hipFree(s->outBuf);
+  if (s->dStats) (void)hipFree(s->dStats);
+  if (s->evStart) (void)hipEventDestroy(s->evStart);
+  if (s->evStop) (void)hipEventDestroy(s->evStop);
+  delete s;
+}
+
+int ptx_counts_device(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, uint32_t* dCounts, void* stream) {
+  FrameConstants fc;
+  int rc = makeFrame(s, cam, prm, true, fc);
+  if (rc) return rc;
+  if (!dCounts) return fail(PTX_EINVAL, "null output");
+  HIP_TRY(hipSetDevice(s->device));
+  return launchCounts(s, fc, dCounts, (hipStream_t)stream, false);
+}
+
+int ptx_render_counts(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, uint32_t* out, ptx_stats* stats) {
+  FrameConstants fc;
+  int rc = makeFrame(s, cam, prm, true, fc);
+  if (rc) return rc;
+  if (!out) return fail(PTX_EINVAL, "null output");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t bytes = (size_t)prm->width * prm->height * sizeof(uint32_t);
+  if ((rc = ensureOut(s, bytes))) return rc;
+  if ((rc = launchCounts(s, fc, (uint32_t*)s->outBuf, nullptr, false))) return rc;
+  HIP_TRY(hipMemcpy(out, s->outBuf, bytes, hipMemcpyDeviceToHost));
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->upload_s = s->uploadSeconds;
+    if ((rc = kernelSeconds(s, &stats->render_s))) return rc;
+  }
+  return PTX_OK;
+}
+
+int ptx_accumulate_device(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, float* dAccum, void* stream) {
+  FrameConstants fc;
+  int rc = makeFrame(s, cam, prm, false, fc);
+  if (rc) return rc;
+  if (!dAccum) return fail(PTX_EINVAL, "null output");
+  if ((uintptr_t)dAccum & 15u) return fail(PTX_EINVAL, "d_accum must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(s->device));
+  return launchRadiance(s, fc, dAccum, false, (hipStream_t)stream, false);
+}
+
+int ptx_resolve_device(ptx_scene* s, const float* dAccum, uint32_t width, uint32_t height, float* dOut, void* stream) {
+  if (!s || !dAccum || !dOut || width == 0 || height == 0) return fail(PTX_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  const uint32_t n = width * height;
+  resolveKernel<<<dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream>>>((const float4*)dAccum, n, dOut);
+  HIP_TRY(hipGetLastError());
+  return PTX_OK;
+}
+
+int ptx_render(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, float* out, ptx_stats* stats) {
+  FrameConstants fc;
+  int rc = makeFrame(s, cam, prm, false, fc);
+  if (rc) return rc;
+  if (!out) return fail(PTX_EINVAL, "null output");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t bytes = (size_t)prm->width * prm->height * 3u * sizeof(float);
+  if ((rc = ensureOut(s, bytes))) return rc;
+  if ((rc = launchRadiance(s, fc, (float*)s->outBuf, true, nullptr, false))) return rc;
+  HIP_TRY(hipMemcpy(out, s->outBuf, bytes, hipMemcpyDeviceToHost));
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->upload_s = s->uploadSeconds;
+    if ((rc = kernelSeconds(s, &stats->render_s))) return rc;
+  }
+  return PTX_OK;
+}
+
+int ptx_measure(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, int heatmap, ptx_stats* stats) {
+  FrameConstants fc;
+  int rc = makeFrame(s, cam, prm, heatmap != 0, fc);
+  if (rc) return rc;
+  if (!stats) return fail(PTX_EINVAL, "null stats");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t bytes = (size_t)prm->width * prm->height * 4u * sizeof(float);
+  if ((rc = ensureOut(s, bytes))) return rc;
+  HIP_TRY(hipMemset(s->dStats, 0, sizeof(DeviceStats)));
+  if (heatmap) rc = launchCounts(s, fc, (uint32_t*)s->outBuf, nullptr, true);
+  else rc = launchRadiance(s, fc, (float*)s->outBuf, false, nullptr, true);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  memset(stats, 0, sizeof(*stats));
+  stats->upload_s = s->uploadSeconds;
+  if ((rc = kernelSeconds(s, &stats->render_s))) return rc;
+  return readStats(s, stats);
+}
+
+int ptx_last_kernel_seconds(ptx_scene* s, double* seconds) {
+  if (!s || !seconds) return fail(PTX_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  return kernelSeconds(s, seconds);
+}
+
+}  // extern "C"
