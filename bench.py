@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s at 1500x800, 100 spp, 6 bounces, Scene 1 (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (the driver launches N>1 through torch.distributed.run; RCCL = backend "nccl").
+A step is one full pass of the hot path: every rank path-traces the whole 1500x800 frame at 100 spp
+with its own RNG stream (sample-slice partition, weak scaling: the job is an N*100-spp frame), the
+un-normalised float accumulation buffers are summed onto rank 0 with one RCCL reduce, and rank 0
+divides, colour-grades and tonemaps.  The scene is resident in HBM before the timed region.
+
+A ray is one call of Scene::intersect (gpuRender.cu:32): rays per step are counted exactly by an
+instrumented launch of the same kernel (paths are deterministic in pixel and seed), outside the
+timed region.  roofline.achieved = algorithmic bytes per launch / kernel time measured with HIP
+events on the launch stream; algorithmic bytes = 64*S + 36*T + 144*I + 12*hits + 12*misses + 12*W*H
+(reference-layout bytes per internal-node step, triangle test, instance entry,
+face normal, environment texel, output pixel).
+
+cpu_baseline (rank 0, N=1 only) times the CPU oracle -- this repository's restatement of the
+reference's `-d 1` path -- on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "path-tracer_amd", "py"))
+
+WIDTH, HEIGHT, SPP, BOUNCES, SCENE = 1500, 800, 100, 6, 1
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(st, width, height, hit_bytes=12):
+    return (64 * st.node_steps + 36 * st.tri_tests + 144 * st.inst_entries + hit_bytes * st.hits + 12 * st.misses
+            + 12 * width * height)
+
+
+def cpu_baseline(scene, budget_s=15.0, threads=None):
+    """Times the oracle on the host cores: same scene/BVH/resolution/bounces, reduced spp."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_binding as ob
+    import ptamd
+    threads = threads or min(os.cpu_count() or 1, 16)  # the GPU box's CPU share for one GPU is 16
+    p = ptamd.make_params(WIDTH, HEIGHT, spp=2, max_bounces=BOUNCES)
+    _, st = ob.render(scene, p, seed_mode=ptamd.SEED_REFERENCE_GPU, threads=threads)
+    per_spp = st.render_s / 2.0
+    spp = int(max(2, min(SPP, budget_s / max(per_spp, 1e-6))))
+    if spp > 2:
+        p = ptamd.make_params(WIDTH, HEIGHT, spp=spp, max_bounces=BOUNCES)
+        _, st = ob.render(scene, p, seed_mode=ptamd.SEED_REFERENCE_GPU, threads=threads)
+    return {
+        "value": st.rays / st.render_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"scene {SCENE} {WIDTH}x{HEIGHT}, {spp} spp of {SPP}, {BOUNCES} bounces, "
+                  f"{st.rays} rays in {st.render_s:.2f} s (oracle/pt_oracle.c, pthreads)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spp", type=int, default=SPP, help=argparse.SUPPRESS)  # profiling runs only
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ptamd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    spp = args.spp
+    scene = ptamd.HostScene(SCENE)  # replicated on every GPU
+    dscene = ptamd.DeviceScene(scene.desc_ptr, device=local_rank)
+    params = ptamd.make_params(WIDTH, HEIGHT, spp=spp, max_bounces=BOUNCES, seed_mode=ptamd.SEED_STREAM,
+                               part_index=rank, part_count=world)
+    accum = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev)
+    out = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=dev)
+
+    def step():
+        stream = torch.cuda.current_stream().cuda_stream
+        dscene.accumulate_device(scene.camera, params, accum.data_ptr(), stream)
+        if world > 1:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: W*H*4 floats, once per frame
+        if rank == 0:
+            dscene.resolve_device(accum.data_ptr(), WIDTH, HEIGHT, out.data_ptr(), stream)
+
+    # exact ray / node / triangle counts of this rank's launch (instrumented kernel, untimed)
+    stats = dscene.measure(scene.camera, params)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kernel_s = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_s.append(dscene.last_kernel_seconds())  # HIP events on the launch stream
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    rays = torch.tensor([float(stats.rays)], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_rays = rays.item()
+    elapsed = tmax.item()
+
+    if rank == 0:
+        img = out.cpu().numpy()
+        if not (img == img).all() or img.min() < 0.0 or img.max() > 1.0 or img.std() == 0.0:
+            raise SystemExit("bench.py: rendered frame failed its sanity check")
+        avg_kernel = sum(kernel_s) / len(kernel_s)
+        alg = algorithmic_bytes(stats, WIDTH, HEIGHT)
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 --pmc passes
+            with open(tpath) as f:
+                t = json.load(f)
+            if t.get("workload") == f"scene{SCENE}_{WIDTH}x{HEIGHT}_{spp}spp_{BOUNCES}b":
+                traffic = t.get("hbm_bytes_per_launch")
+        line = {
+            "metric": "Mrays/s at 1500x800, 100spp, 6 bounces, Scene 1",
+            "value": total_rays * args.steps / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"scene 1 (SCATTER_STL: 10,000 instances of one {scene.info.triangles_per_mesh}-triangle "
+                            f"BLAS, {scene.info.tlas_nodes}-node TLAS) {WIDTH}x{HEIGHT}, {spp} spp per GPU, "
+                            f"{BOUNCES} bounces",
+                "geometry": "procedural stand-in bust (models/bust-of-menelaus.stl absent)"
+                            if scene.info.stand_in_geometry else "bust-of-menelaus.stl",
+                "environment": "analytic stand-in sky (HDR absent)" if scene.info.stand_in_environment else "HDR",
+                "partition": "whole frame per GPU, one RNG stream per GPU, RCCL sum-reduce of W*H*4 f32 to rank 0"
+                             if world > 1 else "single GPU",
+                "rays_per_step": total_rays, "paths_per_step": WIDTH * HEIGHT * spp * world,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": alg / avg_kernel / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg / avg_kernel / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "ptx::radianceKernel", "kernel_ms": avg_kernel * 1e3, "algorithmic_bytes": alg,
+                "node_steps": stats.node_steps, "tri_tests": stats.tri_tests, "inst_entries": stats.inst_entries,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(scene)
+        print(json.dumps(line), flush=True)
+
+    dscene.close()
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

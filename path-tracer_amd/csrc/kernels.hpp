@@ -1,6 +1,28 @@
-// Kernels of the gfx950 backend.  One wave64 owns one 8x8 pixel tile (lane l -> x = l & 7, y = l >> 3),
-// so the 64 primary rays of a wave are spatially adjacent; tiles are handed to workgroups so that the
-// tiles an XCD works on are neighbours (shared BVH nodes stay in that XCD's L2).
+// Kernels of the gfx950 backend.
+//
+// pathKernel is a persistent, wavefront-style state machine: the grid is sized to the chip (not to
+// the image), every lane owns one pixel at a time and pulls the next one from a global work counter
+// when its pixel is finished, and inside the single main loop each lane advances its own ray by one
+// step per iteration:
+//
+//      internal node  : fetch one 64-byte NodePair, two slab tests, order, push far child
+//      BLAS leaf      : one Moeller-Trumbore test
+//      TLAS leaf      : enter the next instance (ray -> object space, marker pushed)
+//      marker popped  : leave the instance (ray -> world space)
+//      traversal done : wait for the shading phase
+//
+// TLAS and BLAS nodes are the same records in one array, so lanes walking the TLAS and lanes inside
+// an instance share the node-step code path.  Lanes whose ray has finished wait until a quarter of
+// the wave (or 12 lanes) is waiting; then the shading phase runs once for all of them: shade the
+// hit / look up the environment, accumulate, write finished pixels, pull new pixels, generate the
+// next ray.  Because every lane always has a ray in flight, a wave is never held hostage by its
+// slowest path, and an image with 100x cost differences between pixels (scene 1) load-balances
+// through the counter.  The traversal stack is one short per-lane stack in LDS ([entry][lane], bank
+// conflict free) that spills to scratch only beyond kLdsStack entries.
+//
+// Per-ray visit order, ray.t at every slab test and every rounding are those of the reference's
+// nested traversal (intersection.hpp:99-233), so the `-a` counts are bit-exact against the CPU
+// path and the radiance path draws the same random numbers as the reference's GPU kernel.
 #pragma once
 
 #include "device_scene.hpp"
@@ -9,116 +31,260 @@
 
 namespace ptx {
 
-// Workgroups are dealt round-robin to the 8 XCDs (blocks b and b+8 share one): give XCD x the x-th
-// contiguous band of tiles.  Bijective for any tile count.
-__device__ __forceinline__ uint32_t xcdBandedTile(uint32_t block, uint32_t nTiles) {
-  const uint32_t xcd = block & 7u, slot = block >> 3;
-  const uint32_t q = nTiles >> 3, r = nTiles & 7u;
-  const uint32_t base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
-  return base + slot;
-}
+constexpr uint32_t kBlockThreads = 256;  // 4 waves
+constexpr uint32_t kLdsStack = 24;       // stack entries per lane kept in LDS (24 KB per block)
+constexpr uint32_t kShadeThreshold = 12; // waiting lanes that trigger the shading phase
 
-__device__ __forceinline__ bool tilePixel(const FrameConstants& fc, uint32_t tile, uint32_t lane, uint32_t& x, uint32_t& y) {
-  const uint32_t ty = tile / fc.tilesX, tx = tile - ty * fc.tilesX;
-  x = tx * 8u + (lane & 7u);
-  y = ty * 8u + (lane >> 3);
-  return x < fc.width && y < fc.height;
-}
+constexpr int kModeCounts = 0;    // `-a`: gpuRender.cu:146-150
+constexpr int kModeRadiance = 1;  // gpuRender.cu:132-169
 
-template <bool STATS>
-__device__ __forceinline__ void flushStats(DeviceStats* stats, uint64_t rays, const TraceCounters& tc, uint64_t hits,
-                                           uint64_t misses, uint64_t boxHits) {
-  if (!STATS) return;
-  atomicAdd(&stats->rays, (unsigned long long)rays);
-  atomicAdd(&stats->nodeSteps, (unsigned long long)tc.nodeSteps);
-  atomicAdd(&stats->triTests, (unsigned long long)tc.triTests);
-  atomicAdd(&stats->instEntries, (unsigned long long)tc.instEntries);
-  atomicAdd(&stats->hits, (unsigned long long)hits);
-  atomicAdd(&stats->misses, (unsigned long long)misses);
-  atomicAdd(&stats->boxHits, (unsigned long long)boxHits);
-}
-
-// `-a` heat map: gpuRender.cu:146-150.  One un-jittered primary ray per pixel; the number of child
-// boxes hit is written as an exact integer.
-template <bool STATS>
-__global__ void __launch_bounds__(64) countsKernel(DeviceScene sc, FrameConstants fc, uint32_t* __restrict__ out,
-                                                   DeviceStats* stats) {
-  const uint32_t nTiles = fc.tilesX * fc.tilesY;
-  const uint32_t tile = xcdBandedTile(blockIdx.x, nTiles);
-  uint32_t x, y;
-  if (!tilePixel(fc, tile, threadIdx.x, x, y)) return;
-  const uint32_t idx = y * fc.width + x;
-  if (fc.partCount > 1u && (tile % fc.partCount) != fc.partIndex) {
-    out[idx] = 0u;
-    return;
+struct LaneStack {
+  uint32_t* lds;  // this lane's column of the block's LDS stack
+  uint32_t spill[kStackEntries - kLdsStack];
+  uint32_t sp;
+  __device__ __forceinline__ void push(uint32_t v) {
+    if (sp < kLdsStack) lds[sp * kBlockThreads] = v;
+    else spill[sp - kLdsStack] = v;
+    sp++;
   }
-  const vec3 o(fc.camPos[0], fc.camPos[1], fc.camPos[2]);
-  const vec3 d = primaryDirection(fc, (float)x, (float)y);
-  const vec3 inv = 1.0f / d;
-  uint32_t count = 0;
-  TraceCounters tc = {0, 0, 0};
-  traceRay<STATS>(sc, o, d, inv, count, tc);
-  out[idx] = count;
-  flushStats<STATS>(stats, 1, tc, 0, 0, count);
+  __device__ __forceinline__ uint32_t pop() {
+    sp--;
+    return sp < kLdsStack ? lds[sp * kBlockThreads] : spill[sp - kLdsStack];
+  }
+};
+
+// Work item -> pixel.  The image is cut into bands of 8 rows; inside a band items run down a column
+// first, so 64 consecutive items (one wave's first fetch) form an 8x8 block of adjacent pixels for
+// any image size, with no padding items.
+__device__ __forceinline__ void workPixel(const FrameConstants& fc, uint32_t w, uint32_t& x, uint32_t& y) {
+  const uint32_t bandItems = fc.width * 8u;
+  const uint32_t band = w / bandItems;
+  const uint32_t r = w - band * bandItems;
+  const uint32_t rows = min(8u, fc.height - band * 8u);
+  const uint32_t cx = r / rows;
+  x = cx;
+  y = band * 8u + (r - cx * rows);
 }
 
-// Radiance: gpuRender.cu:118-170 + getIllumination :24-116.  RESOLVE = true writes the tonemapped
-// pixel (3 floats); false writes the un-normalised sum and the sample count (4 floats) for a
-// multi-GPU reduce.
-template <bool STATS, bool RESOLVE>
-__global__ void __launch_bounds__(64) radianceKernel(DeviceScene sc, FrameConstants fc, float* __restrict__ out,
-                                                     DeviceStats* stats) {
-  const uint32_t nTiles = fc.tilesX * fc.tilesY;
-  const uint32_t tile = xcdBandedTile(blockIdx.x, nTiles);
-  uint32_t x, y;
-  if (!tilePixel(fc, tile, threadIdx.x, x, y)) return;
-  const uint32_t idx = y * fc.width + x;
+template <int MODE, bool STATS, bool RESOLVE>
+__global__ void __launch_bounds__(kBlockThreads) pathKernel(DeviceScene sc, FrameConstants fc, uint32_t* workCounter,
+                                                            void* __restrict__ outRaw, DeviceStats* stats) {
+  __shared__ uint32_t sStack[kLdsStack * kBlockThreads];
+  LaneStack st;
+  st.lds = sStack + threadIdx.x;
+  st.sp = 0;
 
-  uint32_t rng = fc.seedBase + idx;  // gpuRender.cu:130
+  const uint32_t totalWork = fc.width * fc.height;
   const vec3 camPos(fc.camPos[0], fc.camPos[1], fc.camPos[2]);
-  vec3 sum(0.0f);
-  TraceCounters tc = {0, 0, 0};
-  uint64_t rays = 0, hits = 0, misses = 0, boxHits = 0;
 
-  for (uint32_t s = 0; s < fc.spp; s++) {
-    float fx = (float)x, fy = (float)y;
-    if (fc.spp > 1u) {  // gpuRender.cu:133-137
-      const vec2 xi = pt::getRandomVec2(rng);
-      fx += 0.5f * (2.0f * xi.x - 1.0f);
-      fy += 0.5f * (2.0f * xi.y - 1.0f);
-    }
-    vec3 o = camPos;
-    vec3 d = primaryDirection(fc, fx, fy);
-    vec3 col(1.0f);
-    for (uint32_t b = 0; b < fc.maxBounces; b++) {
-      const vec3 inv = 1.0f / d;
-      uint32_t count = 0;
-      const Hit hit = traceRay<STATS>(sc, o, d, inv, count, tc);
-      if (STATS) {
-        rays++;
-        boxHits += count;
+  // ---- lane state ----
+  uint32_t ref = kRefDone;   // node reference the lane processes next
+  bool exhausted = false;    // no more pixels for this lane
+  bool pending = false;      // a traced ray's result waits for the shading phase
+  bool havePixel = false;
+  bool inBlas = false;
+  bool zeroDir = false;      // a component of the current ray's direction is exactly 0 (0*inf possible)
+  uint32_t pix = 0, sample = 0, bounce = 0, rng = 0, count = 0;
+  uint32_t tlasLeaf = 0, curInst = 0;
+  float tBeforeInst = FLT_MAX;
+  vec3 sum(0.0f), col(1.0f);
+  vec3 wo(0.0f), wd(0.0f, 0.0f, -1.0f), winv(0.0f);  // world-space ray
+  vec3 o(0.0f), d(0.0f, 0.0f, -1.0f), inv(0.0f);     // current ray (world or object space)
+  Hit hit;
+  hit.t = FLT_MAX; hit.u = 0.0f; hit.v = 0.0f; hit.tri = 0xFFFFFFFFu; hit.inst = 0xFFFFFFFFu;
+  sample = (MODE == kModeCounts) ? 1u : fc.spp;  // "pixel finished": the first shading phase pulls work
+
+  uint32_t nRays = 0, nNodeSteps = 0, nTriTests = 0, nInstEntries = 0, nHits = 0, nMisses = 0;
+  unsigned long long nBoxHits = 0;
+
+  for (;;) {
+    // =========================== shading phase (postponed, wave-wide) ===========================
+    const bool waiting = !exhausted && ref == kRefDone;
+    const uint32_t nWaiting = (uint32_t)__popcll(__ballot(waiting));
+    const uint32_t nLive = (uint32_t)__popcll(__ballot(!exhausted));
+    if (nLive == 0u) break;
+    if (nWaiting >= kShadeThreshold || nWaiting * 4u >= nLive) {
+      if (waiting) {
+        bool pathEnded = true;
+        if (pending) {
+          pending = false;
+          if (STATS) {
+            nRays++;
+            nBoxHits += count;
+          }
+          if (MODE == kModeCounts) {
+            reinterpret_cast<uint32_t*>(outRaw)[pix] = count;
+          } else if (hit.t < FLT_MAX) {
+            if (STATS) nHits++;
+            shadeHit(sc, hit, wo, wd, rng, col);  // writes the next ray into wo / wd
+            bounce++;
+            pathEnded = bounce >= fc.maxBounces;  // gpuRender.cu:29: the loop ends, col is returned
+          } else {
+            if (STATS) nMisses++;
+            col *= environmentLookup(sc, fc, wd);
+          }
+          if (MODE == kModeRadiance && pathEnded) {
+            sum += col;
+            sample++;
+          }
+        }
+        if (pathEnded) {
+          // ---- pixel finished? write it and pull the next one ----
+          const uint32_t perPixel = (MODE == kModeCounts) ? 1u : fc.spp;
+          while (sample >= perPixel && !exhausted) {
+            if (MODE == kModeRadiance && havePixel) {
+              if (RESOLVE) {
+                const vec3 c = resolvePixel(sum, (float)fc.spp);
+                float* out = reinterpret_cast<float*>(outRaw);
+                out[3ull * pix + 0] = c.x;
+                out[3ull * pix + 1] = c.y;
+                out[3ull * pix + 2] = c.z;
+              } else {
+                reinterpret_cast<float4*>(outRaw)[pix] = make_float4(sum.x, sum.y, sum.z, (float)fc.spp);
+              }
+            }
+            const uint32_t w = atomicAdd(workCounter, 1u);  // aggregated per wave by the compiler
+            if (w >= totalWork) {
+              exhausted = true;
+              havePixel = false;
+              break;
+            }
+            uint32_t x, y;
+            workPixel(fc, w, x, y);
+            pix = y * fc.width + x;
+            sum = vec3(0.0f);
+            rng = fc.seedBase + pix;  // gpuRender.cu:130
+            havePixel = true;
+            sample = 0u;
+            if (MODE == kModeCounts) {
+              if (fc.partCount > 1u) {
+                const uint32_t tile = (y >> 3) * fc.tilesX + (x >> 3);
+                if ((tile % fc.partCount) != fc.partIndex) {
+                  reinterpret_cast<uint32_t*>(outRaw)[pix] = 0u;
+                  sample = 1u;  // not this part's tile: finished
+                }
+              }
+            } else if (fc.maxBounces == 0u) {
+              sum = vec3((float)fc.spp);  // no segment is traced: every path returns white (gpuRender.cu:27-29)
+              sample = fc.spp;
+            }
+          }
+          if (!exhausted) {
+            // ---- next camera ray: gpuRender.cu:132-143 ----
+            const uint32_t py = pix / fc.width, px = pix - py * fc.width;
+            float fx = (float)px, fy = (float)py;
+            if (MODE == kModeRadiance && fc.spp > 1u) {
+              const vec2 xi = pt::getRandomVec2(rng);
+              fx += 0.5f * (2.0f * xi.x - 1.0f);
+              fy += 0.5f * (2.0f * xi.y - 1.0f);
+            }
+            wo = camPos;
+            wd = primaryDirection(fc, fx, fy);
+            col = vec3(1.0f);
+            bounce = 0u;
+            if (MODE == kModeCounts) sample = 1u;  // one ray per pixel
+          }
+        }
+        if (!exhausted) {
+          // ---- launch the segment: Scene::intersect starts at the TLAS root ----
+          winv = 1.0f / wd;
+          o = wo; d = wd; inv = winv;
+          zeroDir = (wd.x == 0.0f) || (wd.y == 0.0f) || (wd.z == 0.0f);
+          hit.t = FLT_MAX; hit.u = 0.0f; hit.v = 0.0f; hit.tri = 0xFFFFFFFFu; hit.inst = 0xFFFFFFFFu;
+          count = 0u;
+          inBlas = false;
+          tlasLeaf = 0u;
+          st.sp = 0u;
+          st.push(kRefDone);
+          ref = sc.tlasRootRef;
+          pending = true;
+        }
       }
-      if (hit.t < FLT_MAX) {
-        if (STATS) hits++;
-        shadeHit(sc, hit, o, d, rng, col);
+    }
+
+    // ================================ one traversal step per lane ================================
+    if (exhausted || ref == kRefDone) continue;
+
+    if (ref == kRefInstExit) {
+      // GPUMesh::intersect returns (ray.t = transformedRay.t); intersectTLAS keeps the instance if it
+      // lowered t (intersection.hpp:184-189).
+      if (hit.t < tBeforeInst) hit.inst = curInst;
+      o = wo; d = wd; inv = winv;
+      zeroDir = (wd.x == 0.0f) || (wd.y == 0.0f) || (wd.z == 0.0f);
+      inBlas = false;
+      if (tlasLeaf) {
+        ref = tlasLeaf;
+        tlasLeaf = 0u;
       } else {
-        if (STATS) misses++;
-        col *= environmentLookup(sc, fc, d);
-        break;
+        ref = st.pop();
+      }
+    } else if (ref & kLeafFlag) {
+      const uint32_t first = ref & 0x00FFFFFFu;
+      const uint32_t n = ((ref >> 24) & 0x7Fu) + 1u;
+      if (!inBlas) {
+        // TLAS leaf: enter instance `first`, keep the rest of the leaf (gpuFunctions.hpp:32-41).
+        tlasLeaf = (n > 1u) ? makeLeafRef(first + 1u, n - 1u) : 0u;
+        curInst = first;
+        const InstXform xf = sc.instXform[first];
+        o = xformRows(xf.row0, xf.row1, xf.row2, wo, 1.0f);
+        d = xformRows(xf.row0, xf.row1, xf.row2, wd, 0.0f);  // not normalised: t stays world-space
+        inv = 1.0f / d;
+        zeroDir = (d.x == 0.0f) || (d.y == 0.0f) || (d.z == 0.0f);
+        tBeforeInst = hit.t;
+        inBlas = true;
+        if (STATS) nInstEntries++;
+        st.push(kRefInstExit);
+        ref = xf.rootRef;
+      } else {
+        // BLAS leaf, one triangle per step, in order, strict `<` (intersection.hpp:112-122).
+        const TriRec tri = sc.tris[first];
+        float u = 0.0f, v = 0.0f;
+        const float dist = triangleTest(o, d, tri, u, v);
+        if (dist < hit.t) {
+          hit.t = dist; hit.u = u; hit.v = v; hit.tri = first;
+        }
+        if (STATS) nTriTests++;
+        ref = (n > 1u) ? makeLeafRef(first + 1u, n - 1u) : st.pop();
+      }
+    } else {
+      // Internal node (intersection.hpp:133-161 / :201-230): one 64-byte record holds both children.
+      const NodePair p = sc.pairs[ref];
+      float d1, d2;
+      if (__any(zeroDir)) {
+        d1 = slabTest<true>(o, inv, hit.t, p.lmin, p.lmax);
+        d2 = slabTest<true>(o, inv, hit.t, p.rmin, p.rmax);
+      } else {
+        d1 = slabTest<false>(o, inv, hit.t, p.lmin, p.lmax);
+        d2 = slabTest<false>(o, inv, hit.t, p.rmin, p.rmax);
+      }
+      uint32_t r1 = __float_as_uint(p.lmin.w), r2 = __float_as_uint(p.rmin.w);
+      if (STATS) nNodeSteps++;
+      if (d1 > d2) {  // nearer child first; ties keep the left child
+        const float td = d1; d1 = d2; d2 = td;
+        const uint32_t tr = r1; r1 = r2; r2 = tr;
+      }
+      if (d1 == FLT_MAX) {
+        ref = st.pop();
+      } else {
+        ref = r1;
+        count++;
+        if (d2 != FLT_MAX) {  // counted when pushed, not re-tested when popped
+          count++;
+          st.push(r2);
+        }
       }
     }
-    sum += col;
   }
 
-  if (RESOLVE) {
-    const vec3 c = resolvePixel(sum, (float)fc.spp);
-    out[3ull * idx + 0] = c.x;
-    out[3ull * idx + 1] = c.y;
-    out[3ull * idx + 2] = c.z;
-  } else {
-    reinterpret_cast<float4*>(out)[idx] = make_float4(sum.x, sum.y, sum.z, (float)fc.spp);
+  if (STATS) {
+    atomicAdd(&stats->rays, (unsigned long long)nRays);
+    atomicAdd(&stats->nodeSteps, (unsigned long long)nNodeSteps);
+    atomicAdd(&stats->triTests, (unsigned long long)nTriTests);
+    atomicAdd(&stats->instEntries, (unsigned long long)nInstEntries);
+    atomicAdd(&stats->hits, (unsigned long long)nHits);
+    atomicAdd(&stats->misses, (unsigned long long)nMisses);
+    atomicAdd(&stats->boxHits, nBoxHits);
   }
-  flushStats<STATS>(stats, rays, tc, hits, misses, boxHits);
 }
 
 // Tail of gpuRender.cu:158-169 on a summed accumulation buffer.

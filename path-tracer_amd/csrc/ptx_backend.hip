@@ -122,6 +122,8 @@ struct ptx_scene {
   void* outBuf = nullptr;
   size_t outBytes = 0;
   DeviceStats* dStats = nullptr;
+  uint32_t* dWorkCounter = nullptr;
+  int numCus = 0;
   hipEvent_t evStart = nullptr, evStop = nullptr;
   hipStream_t lastStream = nullptr;
   bool timed = false;
@@ -184,11 +186,27 @@ int makeFrame(const ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, 
   return PTX_OK;
 }
 
-int launchCounts(ptx_scene* s, const FrameConstants& fc, uint32_t* dOut, hipStream_t stream, bool stats) {
-  const uint32_t nTiles = fc.tilesX * fc.tilesY;
+// Persistent launch: the grid is sized to the chip (CUs x resident blocks per CU), not to the image.
+template <typename K>
+int persistentGrid(ptx_scene* s, K kernel, uint32_t& blocks) {
+  int perCu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, (int)kBlockThreads, 0));
+  if (perCu < 1) perCu = 1;
+  blocks = (uint32_t)(s->numCus * perCu);
+  return PTX_OK;
+}
+
+template <typename K>
+int launchPath(ptx_scene* s, K kernel, const FrameConstants& fc, void* dOut, hipStream_t stream) {
+  uint32_t blocks = 0;
+  int rc = persistentGrid(s, kernel, blocks);
+  if (rc) return rc;
+  const uint32_t work = fc.width * fc.height;
+  const uint32_t needed = (work + kBlockThreads - 1u) / kBlockThreads;
+  if (blocks > needed) blocks = needed;
+  HIP_TRY(hipMemsetAsync(s->dWorkCounter, 0, sizeof(uint32_t), stream));
   HIP_TRY(hipEventRecord(s->evStart, stream));
-  if (stats) countsKernel<true><<<dim3(nTiles), dim3(64), 0, stream>>>(s->dev, fc, dOut, s->dStats);
-  else countsKernel<false><<<dim3(nTiles), dim3(64), 0, stream>>>(s->dev, fc, dOut, s->dStats);
+  kernel<<<dim3(blocks), dim3(kBlockThreads), 0, stream>>>(s->dev, fc, s->dWorkCounter, dOut, s->dStats);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->evStop, stream));
   s->lastStream = stream;
@@ -196,22 +214,18 @@ int launchCounts(ptx_scene* s, const FrameConstants& fc, uint32_t* dOut, hipStre
   return PTX_OK;
 }
 
+int launchCounts(ptx_scene* s, const FrameConstants& fc, uint32_t* dOut, hipStream_t stream, bool stats) {
+  if (stats) return launchPath(s, pathKernel<kModeCounts, true, false>, fc, dOut, stream);
+  return launchPath(s, pathKernel<kModeCounts, false, false>, fc, dOut, stream);
+}
+
 int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool resolve, hipStream_t stream, bool stats) {
-  const uint32_t nTiles = fc.tilesX * fc.tilesY;
-  HIP_TRY(hipEventRecord(s->evStart, stream));
-  const dim3 grid(nTiles), block(64);
   if (stats) {
-    if (resolve) radianceKernel<true, true><<<grid, block, 0, stream>>>(s->dev, fc, dOut, s->dStats);
-    else radianceKernel<true, false><<<grid, block, 0, stream>>>(s->dev, fc, dOut, s->dStats);
-  } else {
-    if (resolve) radianceKernel<false, true><<<grid, block, 0, stream>>>(s->dev, fc, dOut, s->dStats);
-    else radianceKernel<false, false><<<grid, block, 0, stream>>>(s->dev, fc, dOut, s->dStats);
+    if (resolve) return launchPath(s, pathKernel<kModeRadiance, true, true>, fc, dOut, stream);
+    return launchPath(s, pathKernel<kModeRadiance, true, false>, fc, dOut, stream);
   }
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(s->evStop, stream));
-  s->lastStream = stream;
-  s->timed = true;
-  return PTX_OK;
+  if (resolve) return launchPath(s, pathKernel<kModeRadiance, false, true>, fc, dOut, stream);
+  return launchPath(s, pathKernel<kModeRadiance, false, false>, fc, dOut, stream);
 }
 
 int kernelSeconds(ptx_scene* s, double* out) {
@@ -393,7 +407,8 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
       up(oVn, vtxN.data(), vtxN.size() * sizeof(float4)),        up(oUv, d->vtx_uvs, (size_t)d->vtx_uv_total * sizeof(float2)),
       up(oMat, mats.data(), mats.size() * sizeof(MaterialRec)),  up(oTex, texs.data(), texs.size() * sizeof(TextureRec)),
       up(oTexels, texels.data(), texels.size() * sizeof(float4)), up(oEnv, env.data(), env.size() * sizeof(float4)),
-      hipMalloc((void**)&s->dStats, sizeof(DeviceStats)),        hipEventCreate(&s->evStart), hipEventCreate(&s->evStop)};
+      hipMalloc((void**)&s->dStats, sizeof(DeviceStats)),        hipEventCreate(&s->evStart), hipEventCreate(&s->evStop),
+      hipMalloc((void**)&s->dWorkCounter, 256),                  hipDeviceGetAttribute(&s->numCus, hipDeviceAttributeMultiprocessorCount, device)};
   for (hipError_t er : errs)
     if (er != hipSuccess) {
       std::string msg = std::string("scene upload failed: ") + hipGetErrorString(er);
@@ -429,6 +444,7 @@ void ptx_destroy(ptx_scene* s) {
   if (s->arena) (void)hipFree(s->arena);
   if (s->outBuf) (void)hipFree(s->outBuf);
   if (s->dStats) (void)hipFree(s->dStats);
+  if (s->dWorkCounter) (void)hipFree(s->dWorkCounter);
   if (s->evStart) (void)hipEventDestroy(s->evStart);
   if (s->evStop) (void)hipEventDestroy(s->evStop);
   delete s;
