@@ -1,0 +1,90 @@
+"""Frame partitioning across ranks (one process per GPU, torch.distributed: "nccl" = RCCL on ROCm).
+
+The reference is single-GPU; this is the split BASELINE.json asks for:
+
+* radiance -- SAMPLE-SLICE partition: the scene is replicated, rank r path-traces the whole frame
+  with RNG stream r (PTX_SEED_STREAM, part_index = r) for its share of the samples, the
+  un-normalised float accumulation buffers (W*H*4 f32: r, g, b, sample count) are summed onto
+  rank 0 with ONE reduce per frame, and rank 0 divides by the summed sample count, colour-grades and
+  tonemaps.  Rank 0 of a 1-rank job reproduces the reference GPU seeding exactly.
+* heat map (`-a`) -- TILE partition: rank r traces the 8x8 tiles with tile % world == r and writes
+  0 elsewhere, so an integer sum-reduce reassembles the frame exactly (disjoint support).
+
+The render calls go through a `backend` object so that the same orchestration runs on GPUs
+(HipBackend: C ABI + RCCL) and, in the CPU tests, on the oracle with the gloo backend.
+"""
+import numpy as np
+
+
+def split_samples(total_spp, world):
+    """Samples per rank for a fixed-size job: the first (total % world) ranks take one extra."""
+    base, extra = divmod(total_spp, world)
+    return [base + (1 if r < extra else 0) for r in range(world)]
+
+
+class HipBackend:
+    """Device buffers are torch CUDA tensors; kernels are launched through the C ABI on torch's
+    current stream so that they are ordered with the RCCL collective."""
+
+    def __init__(self, host_scene, device_index=0):
+        import torch
+        import ptamd
+        self.torch = torch
+        self.ptamd = ptamd
+        self.host = host_scene
+        self.device = torch.device("cuda", device_index)
+        self.dscene = ptamd.DeviceScene(host_scene.desc_ptr, device=device_index)
+        self._accum = {}
+
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def accumulate(self, params):
+        key = (params.height, params.width)
+        if key not in self._accum:
+            self._accum[key] = self.torch.empty((params.height, params.width, 4), dtype=self.torch.float32,
+                                                device=self.device)
+        buf = self._accum[key]
+        self.dscene.accumulate_device(self.host.camera, params, buf.data_ptr(), self._stream())
+        return buf
+
+    def resolve(self, accum):
+        h, w = accum.shape[:2]
+        out = self.torch.empty((h, w, 3), dtype=self.torch.float32, device=self.device)
+        self.dscene.resolve_device(accum.data_ptr(), w, h, out.data_ptr(), self._stream())
+        return out
+
+    def counts(self, params):
+        buf = self.torch.empty((params.height, params.width), dtype=self.torch.int32, device=self.device)
+        self.dscene.counts_device(self.host.camera, params, buf.data_ptr(), self._stream())
+        return buf
+
+    def close(self):
+        self.dscene.close()
+
+
+def render_radiance(backend, make_params, width, height, spp_this_rank, max_bounces, rank, world, dist=None):
+    """One frame.  Returns the tonemapped (H, W, 3) tensor on rank 0, None elsewhere."""
+    import ptamd
+    seed_mode = ptamd.SEED_REFERENCE_GPU if world == 1 else ptamd.SEED_STREAM
+    params = make_params(width, height, spp=spp_this_rank, max_bounces=max_bounces, seed_mode=seed_mode,
+                         part_index=rank, part_count=world)
+    accum = backend.accumulate(params)
+    if world > 1:
+        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        return backend.resolve(accum)
+    return None
+
+
+def render_counts(backend, make_params, width, height, rank, world, dist=None):
+    """`-a` frame: exact integer counts on rank 0 (None elsewhere)."""
+    params = make_params(width, height, part_index=rank, part_count=world)
+    counts = backend.counts(params)
+    if world > 1:
+        dist.reduce(counts, dst=0, op=dist.ReduceOp.SUM)
+    return counts if rank == 0 else None
+
+
+def to_numpy(t):
+    return np.asarray(t.detach().cpu().numpy()) if hasattr(t, "detach") else np.asarray(t)
