@@ -34,7 +34,7 @@ constexpr uint32_t kMaxPrimIndex = 0x00FFFFF0u;
 // Far children deferred on the stack never exceed the depth of the tree being walked; TLAS depth +
 // BLAS depth + the two markers must fit (checked in ptx_create; the reference uses two unchecked
 // 32-entry stacks, intersection.hpp:97).
-constexpr uint32_t kStackEntries = 96u;
+constexpr uint32_t kStackEntries = 256u;
 
 __host__ __device__ inline uint32_t makeLeafRef(uint32_t first, uint32_t count) {
   return kLeafFlag | ((count - 1u) << 24) | first;
@@ -81,6 +81,8 @@ struct TextureRec {  // 16 B
 };
 
 struct DeviceScene {
+  const float4* arena;   // base of the one allocation; the three traversal arrays are also addressed
+  uint32_t pairs16, tris16, inst16;  // from here, as offsets in 16-byte units (unified 64-byte fetch)
   const NodePair* pairs;
   const TriRec* tris;
   const InstXform* instXform;

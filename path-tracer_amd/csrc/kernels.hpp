@@ -33,25 +33,57 @@ namespace ptx {
 
 constexpr uint32_t kBlockThreads = 256;  // 4 waves
 constexpr uint32_t kLdsStack = 24;       // stack entries per lane kept in LDS (24 KB per block)
-constexpr uint32_t kShadeThreshold = 12; // waiting lanes that trigger the shading phase
+// Lanes waiting in a state before its body is run for them (tunable; see DESIGN.md "Scheduling").
+#ifndef PTX_SHADE_THRESHOLD
+#define PTX_SHADE_THRESHOLD 12
+#endif
+#ifndef PTX_TRI_THRESHOLD
+#define PTX_TRI_THRESHOLD 1
+#endif
+#ifndef PTX_ENTER_THRESHOLD
+#define PTX_ENTER_THRESHOLD 1
+#endif
+#ifndef PTX_EXIT_THRESHOLD
+#define PTX_EXIT_THRESHOLD 1
+#endif
+constexpr uint32_t kShadeThreshold = PTX_SHADE_THRESHOLD;
 
 constexpr int kModeCounts = 0;    // `-a`: gpuRender.cu:146-150
 constexpr int kModeRadiance = 1;  // gpuRender.cu:132-169
 
-struct LaneStack {
-  uint32_t* lds;  // this lane's column of the block's LDS stack
-  uint32_t spill[kStackEntries - kLdsStack];
-  uint32_t sp;
-  __device__ __forceinline__ void push(uint32_t v) {
-    if (sp < kLdsStack) lds[sp * kBlockThreads] = v;
-    else spill[sp - kLdsStack] = v;
-    sp++;
-  }
-  __device__ __forceinline__ uint32_t pop() {
-    sp--;
-    return sp < kLdsStack ? lds[sp * kBlockThreads] : spill[sp - kLdsStack];
-  }
+// Per-lane traversal stack: entries [0, kLdsStack) live in LDS as sStack[entry][thread] (consecutive
+// lanes -> consecutive banks); deeper entries go to a per-launch global overflow buffer laid out
+// [entry][global thread] (coalesced; touched only by rays that really go that deep).  The main loop
+// touches the stack exactly twice per iteration for every lane -- an early read of the top entry,
+// overlapped with the global fetch, and one write of the slot above the top (a write that is not
+// followed by sp++ leaves garbage above the top, which is harmless) -- so the common path has no
+// branches; a wave-uniform test diverts to the LDS-or-overflow path only while some lane of the wave
+// is near the LDS capacity.
+struct StackMem {
+  uint32_t* lds;       // &sStack[threadIdx.x]
+  uint32_t* overflow;  // &overflowBase[global thread]
+  uint32_t stride;     // total threads of the launch
 };
+__device__ __forceinline__ uint32_t stackRead(const StackMem& m, uint32_t slot, bool deep) {
+  uint32_t v;
+  if (!deep) {
+    v = m.lds[slot * kBlockThreads];
+  } else {
+    // both loads, then a value select: a pointer select would become a (slow, doubly counted) flat load
+    const uint32_t a = m.lds[(slot < kLdsStack ? slot : kLdsStack - 1u) * kBlockThreads];
+    const uint32_t b = m.overflow[(size_t)(slot < kLdsStack ? 0u : slot - kLdsStack) * m.stride];
+    v = slot < kLdsStack ? a : b;
+  }
+  return v;
+}
+__device__ __forceinline__ void stackWrite(const StackMem& m, uint32_t slot, uint32_t val, bool deep) {
+  if (!deep) {
+    m.lds[slot * kBlockThreads] = val;
+  } else {
+    if (slot < kLdsStack) m.lds[slot * kBlockThreads] = val;
+    else m.overflow[(size_t)(slot - kLdsStack) * m.stride] = val;
+  }
+}
 
 // Work item -> pixel.  The image is cut into bands of 8 rows; inside a band items run down a column
 // first, so 64 consecutive items (one wave's first fetch) form an 8x8 block of adjacent pixels for
@@ -68,11 +100,14 @@ __device__ __forceinline__ void workPixel(const FrameConstants& fc, uint32_t w, 
 
 template <int MODE, bool STATS, bool RESOLVE>
 __global__ void __launch_bounds__(kBlockThreads) pathKernel(DeviceScene sc, FrameConstants fc, uint32_t* workCounter,
-                                                            void* __restrict__ outRaw, DeviceStats* stats) {
+                                                            void* __restrict__ outRaw, DeviceStats* stats,
+                                                            uint32_t* stackOverflow) {
   __shared__ uint32_t sStack[kLdsStack * kBlockThreads];
-  LaneStack st;
-  st.lds = sStack + threadIdx.x;
-  st.sp = 0;
+  StackMem stk;
+  stk.lds = sStack + threadIdx.x;
+  stk.overflow = stackOverflow + (blockIdx.x * kBlockThreads + threadIdx.x);
+  stk.stride = gridDim.x * kBlockThreads;
+  uint32_t sp = 1;
 
   const uint32_t totalWork = fc.width * fc.height;
   const vec3 camPos(fc.camPos[0], fc.camPos[1], fc.camPos[2]);
@@ -194,8 +229,8 @@ __global__ void __launch_bounds__(kBlockThreads) pathKernel(DeviceScene sc, Fram
           count = 0u;
           inBlas = false;
           tlasLeaf = 0u;
-          st.sp = 0u;
-          st.push(kRefDone);
+          sStack[threadIdx.x] = kRefDone;  // slot 0: bottom-of-stack marker
+          sp = 1u;
           ref = sc.tlasRootRef;
           pending = true;
         }
@@ -203,76 +238,100 @@ __global__ void __launch_bounds__(kBlockThreads) pathKernel(DeviceScene sc, Fram
     }
 
     // ================================ one traversal step per lane ================================
-    if (exhausted || ref == kRefDone) continue;
+    // Every lane is in exactly one state.  All lanes first issue the same three memory operations --
+    // the LDS read of their stack top and ONE 64-byte fetch of the record their state needs (NodePair,
+    // TriRec or InstXform, all in one arena) -- so an iteration pays one memory latency, not one per
+    // state; the state bodies then run from registers, predicated, without further loads.
+    const bool active = !exhausted && ref != kRefDone;
+    const bool isExit = active && ref == kRefInstExit;
+    const bool isLeaf = active && !isExit && (ref & kLeafFlag) != 0u;
+    const bool isEnter = isLeaf && !inBlas;
+    const bool isTri = isLeaf && inBlas;
+    const bool isNode = active && (ref & kLeafFlag) == 0u;
+    const uint32_t first = ref & 0x00FFFFFFu;
+    const uint32_t nPrim = ((ref >> 24) & 0x7Fu) + 1u;
 
-    if (ref == kRefInstExit) {
+    const bool deep = __any(sp + 2u >= kLdsStack);  // wave-uniform; false almost always
+    const uint32_t top = stackRead(stk, sp ? sp - 1u : 0u, deep);
+
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+    if (active && !isExit) {
+      // record address in 16-byte units from the arena base
+      const uint32_t off16 = isNode ? sc.pairs16 + ref * 4u : (isTri ? sc.tris16 + first * 3u : sc.inst16 + first * 4u);
+      const float4* rp = sc.arena + off16;
+      r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3];
+    }
+
+    uint32_t newRef = ref;
+    uint32_t pushVal = 0u;
+    bool doPush = false, doPop = false;
+
+    if (isExit) {
       // GPUMesh::intersect returns (ray.t = transformedRay.t); intersectTLAS keeps the instance if it
       // lowered t (intersection.hpp:184-189).
       if (hit.t < tBeforeInst) hit.inst = curInst;
       o = wo; d = wd; inv = winv;
       zeroDir = (wd.x == 0.0f) || (wd.y == 0.0f) || (wd.z == 0.0f);
       inBlas = false;
-      if (tlasLeaf) {
-        ref = tlasLeaf;
-        tlasLeaf = 0u;
-      } else {
-        ref = st.pop();
+      doPop = tlasLeaf == 0u;
+      newRef = doPop ? top : tlasLeaf;
+      tlasLeaf = 0u;
+    }
+    if (isEnter) {
+      // TLAS leaf: enter its first instance, keep the rest of the leaf (gpuFunctions.hpp:32-41).
+      tlasLeaf = (nPrim > 1u) ? makeLeafRef(first + 1u, nPrim - 1u) : 0u;
+      curInst = first;
+      o = xformRows(r0, r1, r2, wo, 1.0f);
+      d = xformRows(r0, r1, r2, wd, 0.0f);  // not normalised: t stays world-space
+      inv = 1.0f / d;
+      zeroDir = (d.x == 0.0f) || (d.y == 0.0f) || (d.z == 0.0f);
+      tBeforeInst = hit.t;
+      inBlas = true;
+      if (STATS) nInstEntries++;
+      pushVal = kRefInstExit;
+      doPush = true;
+      newRef = __float_as_uint(r3.x);  // InstXform::rootRef
+    }
+    if (isTri) {
+      // BLAS leaf, one triangle per step, in order, strict `<` (intersection.hpp:9-44, :112-122).
+      TriRec tri;
+      tri.v0 = r0; tri.e1 = r1; tri.e2 = r2;
+      float u = 0.0f, v = 0.0f;
+      const float dist = triangleTest(o, d, tri, u, v);
+      if (dist < hit.t) {
+        hit.t = dist; hit.u = u; hit.v = v; hit.tri = first;
       }
-    } else if (ref & kLeafFlag) {
-      const uint32_t first = ref & 0x00FFFFFFu;
-      const uint32_t n = ((ref >> 24) & 0x7Fu) + 1u;
-      if (!inBlas) {
-        // TLAS leaf: enter instance `first`, keep the rest of the leaf (gpuFunctions.hpp:32-41).
-        tlasLeaf = (n > 1u) ? makeLeafRef(first + 1u, n - 1u) : 0u;
-        curInst = first;
-        const InstXform xf = sc.instXform[first];
-        o = xformRows(xf.row0, xf.row1, xf.row2, wo, 1.0f);
-        d = xformRows(xf.row0, xf.row1, xf.row2, wd, 0.0f);  // not normalised: t stays world-space
-        inv = 1.0f / d;
-        zeroDir = (d.x == 0.0f) || (d.y == 0.0f) || (d.z == 0.0f);
-        tBeforeInst = hit.t;
-        inBlas = true;
-        if (STATS) nInstEntries++;
-        st.push(kRefInstExit);
-        ref = xf.rootRef;
-      } else {
-        // BLAS leaf, one triangle per step, in order, strict `<` (intersection.hpp:112-122).
-        const TriRec tri = sc.tris[first];
-        float u = 0.0f, v = 0.0f;
-        const float dist = triangleTest(o, d, tri, u, v);
-        if (dist < hit.t) {
-          hit.t = dist; hit.u = u; hit.v = v; hit.tri = first;
-        }
-        if (STATS) nTriTests++;
-        ref = (n > 1u) ? makeLeafRef(first + 1u, n - 1u) : st.pop();
-      }
-    } else {
+      if (STATS) nTriTests++;
+      doPop = nPrim == 1u;
+      newRef = doPop ? top : makeLeafRef(first + 1u, nPrim - 1u);
+    }
+    if (isNode) {
       // Internal node (intersection.hpp:133-161 / :201-230): one 64-byte record holds both children.
-      const NodePair p = sc.pairs[ref];
       float d1, d2;
       if (__any(zeroDir)) {
-        d1 = slabTest<true>(o, inv, hit.t, p.lmin, p.lmax);
-        d2 = slabTest<true>(o, inv, hit.t, p.rmin, p.rmax);
+        d1 = slabTest<true>(o, inv, hit.t, r0, r1);
+        d2 = slabTest<true>(o, inv, hit.t, r2, r3);
       } else {
-        d1 = slabTest<false>(o, inv, hit.t, p.lmin, p.lmax);
-        d2 = slabTest<false>(o, inv, hit.t, p.rmin, p.rmax);
+        d1 = slabTest<false>(o, inv, hit.t, r0, r1);
+        d2 = slabTest<false>(o, inv, hit.t, r2, r3);
       }
-      uint32_t r1 = __float_as_uint(p.lmin.w), r2 = __float_as_uint(p.rmin.w);
+      const uint32_t rl = __float_as_uint(r0.w), rr = __float_as_uint(r2.w);
       if (STATS) nNodeSteps++;
-      if (d1 > d2) {  // nearer child first; ties keep the left child
-        const float td = d1; d1 = d2; d2 = td;
-        const uint32_t tr = r1; r1 = r2; r2 = tr;
-      }
-      if (d1 == FLT_MAX) {
-        ref = st.pop();
-      } else {
-        ref = r1;
-        count++;
-        if (d2 != FLT_MAX) {  // counted when pushed, not re-tested when popped
-          count++;
-          st.push(r2);
-        }
-      }
+      const bool swap = d1 > d2;  // nearer child first; ties keep the left child
+      const float dn = swap ? d2 : d1, df = swap ? d1 : d2;
+      const uint32_t rn = swap ? rr : rl, rf = swap ? rl : rr;
+      const bool hitNear = dn != FLT_MAX, hitFar = df != FLT_MAX;  // far hit implies near hit
+      count += (hitNear ? 1u : 0u) + (hitFar ? 1u : 0u);  // counted when pushed, not re-tested when popped
+      pushVal = rf;
+      doPush = hitFar;
+      doPop = !hitNear;
+      newRef = hitNear ? rn : top;
+    }
+
+    if (active) {
+      stackWrite(stk, sp, pushVal, deep);
+      sp = sp + (doPush ? 1u : 0u) - (doPop ? 1u : 0u);
+      ref = newRef;
     }
   }
 

@@ -123,6 +123,8 @@ struct ptx_scene {
   size_t outBytes = 0;
   DeviceStats* dStats = nullptr;
   uint32_t* dWorkCounter = nullptr;
+  uint32_t* dOverflow = nullptr;  // traversal-stack overflow area (grown on demand)
+  size_t ovfBytes = 0;
   int numCus = 0;
   hipEvent_t evStart = nullptr, evStop = nullptr;
   hipStream_t lastStream = nullptr;
@@ -204,9 +206,20 @@ int launchPath(ptx_scene* s, K kernel, const FrameConstants& fc, void* dOut, hip
   const uint32_t work = fc.width * fc.height;
   const uint32_t needed = (work + kBlockThreads - 1u) / kBlockThreads;
   if (blocks > needed) blocks = needed;
+  // overflow area of the traversal stack: entries beyond the LDS part, [entry][thread]
+  const uint32_t bound = s->tlasDepth + s->blasDepth + 2u;
+  const size_t deepEntries = bound > kLdsStack ? bound - kLdsStack : 0u;
+  const size_t ovfBytes = (deepEntries ? deepEntries : 1u) * (size_t)blocks * kBlockThreads * sizeof(uint32_t);
+  if (s->ovfBytes < ovfBytes) {
+    if (s->dOverflow) HIP_TRY(hipFree(s->dOverflow));
+    s->dOverflow = nullptr;
+    s->ovfBytes = 0;
+    HIP_TRY(hipMalloc((void**)&s->dOverflow, ovfBytes));
+    s->ovfBytes = ovfBytes;
+  }
   HIP_TRY(hipMemsetAsync(s->dWorkCounter, 0, sizeof(uint32_t), stream));
   HIP_TRY(hipEventRecord(s->evStart, stream));
-  kernel<<<dim3(blocks), dim3(kBlockThreads), 0, stream>>>(s->dev, fc, s->dWorkCounter, dOut, s->dStats);
+  kernel<<<dim3(blocks), dim3(kBlockThreads), 0, stream>>>(s->dev, fc, s->dWorkCounter, dOut, s->dStats, s->dOverflow);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->evStop, stream));
   s->lastStream = stream;
@@ -305,7 +318,7 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
     geomShade[g].vtxNormalBase = G.vtx_normal_offset;
     geomShade[g].vtxUvBase = G.vtx_uv_offset;
   }
-  if (tlas.depth + blasDepth + 2u > kStackEntries) {
+  if (tlas.depth + blasDepth + 2u > kStackEntries) {  // sanity bound on the overflow area
     char buf[160];
     snprintf(buf, sizeof(buf), "BVH too deep for the traversal stack: TLAS depth %u + BLAS depth %u + 2 > %u", tlas.depth,
              blasDepth, kStackEntries);
@@ -385,7 +398,9 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
   const size_t oTex = arenaReserve<TextureRec>(cur, texs.size() ? texs.size() : 1);
   const size_t oTexels = arenaReserve<float4>(cur, texels.size() ? texels.size() : 1);
   const size_t oEnv = arenaReserve<float4>(cur, env.size());
-  cur = (cur + 255u) & ~size_t(255);
+  cur = ((cur + 255u) & ~size_t(255)) + 256u;  // tail pad: the unified fetch reads 64 B from a 48-B TriRec
+  if (oIx / 16 + (uint64_t)ix.size() * 4u >= (1ull << 32) || oTris / 16 + (uint64_t)tris.size() * 3u >= (1ull << 32))
+    return fail(PTX_ELIMIT, "traversal arrays exceed the 64 GiB addressable by 16-byte offsets");
 
   HIP_TRY(hipSetDevice(device));
   ptx_scene* s = new ptx_scene();
@@ -416,6 +431,10 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
       return fail(PTX_EHIP, msg);
     }
   DeviceScene& D = s->dev;
+  D.arena = (const float4*)base;
+  D.pairs16 = (uint32_t)(oPairs / 16);
+  D.tris16 = (uint32_t)(oTris / 16);
+  D.inst16 = (uint32_t)(oIx / 16);
   D.pairs = (const NodePair*)(base + oPairs);
   D.tris = (const TriRec*)(base + oTris);
   D.instXform = (const InstXform*)(base + oIx);
@@ -445,6 +464,7 @@ void ptx_destroy(ptx_scene* s) {
   if (s->outBuf) (void)hipFree(s->outBuf);
   if (s->dStats) (void)hipFree(s->dStats);
   if (s->dWorkCounter) (void)hipFree(s->dWorkCounter);
+  if (s->dOverflow) (void)hipFree(s->dOverflow);
   if (s->evStart) (void)hipEventDestroy(s->evStart);
   if (s->evStop) (void)hipEventDestroy(s->evStop);
   delete s;

@@ -15,6 +15,14 @@ using pt::vec3;
 
 __device__ __forceinline__ vec3 f4xyz(const float4& q) { return vec3(q.x, q.y, q.z); }
 
+// v_min_f32 / v_max_f32 / v_max3_f32 / v_min3_f32 written as asm so that the compiler does not put a
+// canonicalising v_max_f32 x, x in front of every operand (it cannot prove the products are not
+// signalling NaNs; the instructions themselves handle any input).
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 // intersection.hpp:48-75 with glm::min/max semantics: min(x,y) = (y<x)?y:x, max(x,y) = (x<y)?y:x.
 // EXACT_NAN = false uses v_min_f32 / v_max_f32 (IEEE minNum/maxNum), which return the same value as
 // GLM's forms for every non-NaN input (a zero may differ in sign, which no comparison below can see).
@@ -30,32 +38,34 @@ __device__ __forceinline__ float slabTest(const vec3& o, const vec3& inv, float 
     tmin = pt::gmax(pt::gmax(pt::gmin(t1x, t2x), pt::gmin(t1y, t2y)), pt::gmin(t1z, t2z));
     tmax = pt::gmin(pt::gmin(pt::gmax(t1x, t2x), pt::gmax(t1y, t2y)), pt::gmax(t1z, t2z));
   } else {
-    tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-    tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+    tmin = vmax3(vmin(t1x, t2x), vmin(t1y, t2y), vmin(t1z, t2z));
+    tmax = vmin3(vmax(t1x, t2x), vmax(t1y, t2y), vmax(t1z, t2z));
   }
   return (tmax >= tmin && tmin < rayT && tmax > 0.0f) ? tmin : FLT_MAX;
 }
 
 // intersection.hpp:9-44 on a TriRec (edges precomputed on the host with the same subtractions).
+// Written without early returns: every lane evaluates the whole test and the reference's five
+// rejection conditions are combined at the end, each with the reference's own comparison (so a NaN
+// from a degenerate determinant passes or fails exactly where it does there; a rejected lane's later
+// values are never used).
 __device__ __forceinline__ float triangleTest(const vec3& o, const vec3& d, const TriRec& tri, float& u, float& v) {
   const vec3 edge1 = f4xyz(tri.e1), edge2 = f4xyz(tri.e2);
   const vec3 h = pt::cross(d, edge2);
   const float a = pt::dot(edge1, h);
-  if (a > -1e-4f && a < 1e-4f) return FLT_MAX;
+  const bool parallel = a > -1e-4f && a < 1e-4f;
   const float f = 1.0f / a;
   const vec3 s = o - f4xyz(tri.v0);
   const float uu = f * pt::dot(s, h);
-  if (uu < 0.0f || uu > 1.0f) return FLT_MAX;
+  const bool uOut = uu < 0.0f || uu > 1.0f;
   const vec3 q = pt::cross(s, edge1);
   const float vv = f * pt::dot(d, q);
-  if (vv < 0.0f || uu + vv > 1.0f) return FLT_MAX;
+  const bool vOut = vv < 0.0f || uu + vv > 1.0f;
   const float t = f * pt::dot(edge2, q);
-  if (t > 0.0f) {
-    u = uu;
-    v = vv;
-    return t;
-  }
-  return FLT_MAX;
+  const bool ok = !parallel && !uOut && !vOut && t > 0.0f;
+  u = uu;
+  v = vv;
+  return ok ? t : FLT_MAX;
 }
 
 // glm mat4 * vec4(v, w) restricted to xyz: (m0*x + m1*y) + (m2*z + m3*w) per row.

@@ -226,7 +226,8 @@ BACKEND_SYMBOLS = [
 def backend_lib():
     global _backend
     if _backend is None:
-        path = os.path.join(LIB_DIR, "libptx_backend.so")
+        # PTX_BACKEND_LIB selects an experimental build of the same library (tools/build_variants.sh)
+        path = os.environ.get("PTX_BACKEND_LIB", os.path.join(LIB_DIR, "libptx_backend.so"))
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `make backend` (or __graft_entry__.build()); "
                                "there is no CPU fallback for the render path")
