@@ -15,9 +15,11 @@
 //   InstShade 64 B   rows of the normal matrix + geometry / material ids (touched only on a hit)
 //   MaterialRec 64 B, GeomShade 16 B, float4 normals / texels / environment
 //
-// A node reference is one dword: bit 31 clear -> index of a NodePair (internal node);
-// bit 31 set -> leaf: bits 30..24 = primitive count - 1, bits 23..0 = first primitive (absolute
-// triangle index for a BLAS, instance index for the TLAS).
+// A node reference is one dword that also encodes what a lane has to do next:
+//   0x00000000..0x7FFFFFFF  internal node: index of its NodePair
+//   0x80000000..0xBFFFFFFF  BLAS leaf:  bits 29..23 = triangle count - 1, bits 22..0 = first triangle (absolute)
+//   0xC0000000..0xFFFFFFFC  TLAS leaf:  bits 29..24 = instance count - 1, bits 23..0 = first instance
+//   0xFFFFFFFD / E / F      lane idle / traversal done / leave the current instance
 #pragma once
 
 #include <stdint.h>
@@ -27,17 +29,22 @@
 namespace ptx {
 
 constexpr uint32_t kLeafFlag = 0x80000000u;
+constexpr uint32_t kTlasLeafFlag = 0xC0000000u;
+constexpr uint32_t kRefIdle = 0xFFFFFFFDu;      // the lane has no more pixels
 constexpr uint32_t kRefDone = 0xFFFFFFFEu;      // bottom-of-stack marker: traversal finished
 constexpr uint32_t kRefInstExit = 0xFFFFFFFFu;  // pushed when a BLAS is entered: instance finished
-constexpr uint32_t kMaxLeafPrims = 128u;
-constexpr uint32_t kMaxPrimIndex = 0x00FFFFF0u;
+constexpr uint32_t kMaxBlasLeafPrims = 128u, kMaxTlasLeafPrims = 64u;
+constexpr uint32_t kMaxTriIndex = 0x007FFFFFu, kMaxInstIndex = 0x00FFFFF0u;
 // Far children deferred on the stack never exceed the depth of the tree being walked; TLAS depth +
-// BLAS depth + the two markers must fit (checked in ptx_create; the reference uses two unchecked
-// 32-entry stacks, intersection.hpp:97).
+// BLAS depth + the two markers bound the stack (the reference uses two unchecked 32-entry stacks,
+// intersection.hpp:97).  Entries beyond the LDS part go to a global overflow area sized from the bound.
 constexpr uint32_t kStackEntries = 256u;
 
 __host__ __device__ inline uint32_t makeLeafRef(uint32_t first, uint32_t count) {
-  return kLeafFlag | ((count - 1u) << 24) | first;
+  return kLeafFlag | ((count - 1u) << 23) | first;
+}
+__host__ __device__ inline uint32_t makeTlasLeafRef(uint32_t first, uint32_t count) {
+  return kTlasLeafFlag | ((count - 1u) << 24) | first;
 }
 
 struct NodePair {   // 64 B

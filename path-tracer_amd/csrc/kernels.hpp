@@ -2,23 +2,28 @@
 //
 // pathKernel is a persistent, wavefront-style state machine: the grid is sized to the chip (not to
 // the image), every lane owns one pixel at a time and pulls the next one from a global work counter
-// when its pixel is finished, and inside the single main loop each lane advances its own ray by one
-// step per iteration:
+// when its pixel is finished, and inside the main loop each lane advances its own ray by one step
+// per iteration.  The lane's whole traversal state is the one-dword node reference it holds
+// (device_scene.hpp):
 //
-//      internal node  : fetch one 64-byte NodePair, two slab tests, order, push far child
+//      internal node  : two slab tests on one 64-byte NodePair, order, push far child
 //      BLAS leaf      : one Moeller-Trumbore test
 //      TLAS leaf      : enter the next instance (ray -> object space, marker pushed)
-//      marker popped  : leave the instance (ray -> world space)
-//      traversal done : wait for the shading phase
+//      kRefInstExit   : leave the instance (ray -> world space)
+//      kRefDone       : traversal finished, wait for the shading phase
+//      kRefIdle       : no pixels left
 //
-// TLAS and BLAS nodes are the same records in one array, so lanes walking the TLAS and lanes inside
-// an instance share the node-step code path.  Lanes whose ray has finished wait until a quarter of
-// the wave (or 12 lanes) is waiting; then the shading phase runs once for all of them: shade the
-// hit / look up the environment, accumulate, write finished pixels, pull new pixels, generate the
-// next ray.  Because every lane always has a ray in flight, a wave is never held hostage by its
-// slowest path, and an image with 100x cost differences between pixels (scene 1) load-balances
-// through the counter.  The traversal stack is one short per-lane stack in LDS ([entry][lane], bank
-// conflict free) that spills to scratch only beyond kLdsStack entries.
+// Every iteration all lanes issue the same memory operations first -- an LDS read of their stack
+// top and ONE 64-byte fetch of the record their state needs (NodePair, TriRec or InstXform live in
+// one arena and are addressed from its base) -- so an iteration pays one memory latency, not one
+// per state; the state bodies then run from registers, predicated, and the iteration ends with one
+// LDS write of the slot above the stack top.  TLAS and BLAS nodes are the same records, so lanes
+// walking the TLAS and lanes inside an instance share the node-step code.  Lanes whose ray has
+// finished wait until a quarter of the wave (or PTX_SHADE_THRESHOLD lanes) is waiting; then the
+// shading phase runs once for all of them: shade the hit / look up the environment, accumulate,
+// write finished pixels, pull new pixels, generate the next ray.  Because every lane always has a
+// ray in flight, a wave is never held hostage by its slowest path, and an image with 100x cost
+// differences between pixels (scene 1) load-balances through the counter.
 //
 // Per-ray visit order, ray.t at every slab test and every rounding are those of the reference's
 // nested traversal (intersection.hpp:99-233), so the `-a` counts are bit-exact against the CPU
@@ -33,20 +38,16 @@ namespace ptx {
 
 constexpr uint32_t kBlockThreads = 256;  // 4 waves
 constexpr uint32_t kLdsStack = 24;       // stack entries per lane kept in LDS (24 KB per block)
-// Lanes waiting in a state before its body is run for them (tunable; see DESIGN.md "Scheduling").
+// Tunables (see DESIGN.md "Scheduling inside a wave").
 #ifndef PTX_SHADE_THRESHOLD
-#define PTX_SHADE_THRESHOLD 12
-#endif
-#ifndef PTX_TRI_THRESHOLD
-#define PTX_TRI_THRESHOLD 1
+#define PTX_SHADE_THRESHOLD 12  // waiting lanes that trigger the shading phase
 #endif
 #ifndef PTX_ENTER_THRESHOLD
-#define PTX_ENTER_THRESHOLD 1
+#define PTX_ENTER_THRESHOLD 1   // lanes at a TLAS leaf before the (rare, long) instance-entry body is run
 #endif
-#ifndef PTX_EXIT_THRESHOLD
-#define PTX_EXIT_THRESHOLD 1
+#ifndef PTX_INNER_ITERS
+#define PTX_INNER_ITERS 1       // traversal iterations between two checks for the shading phase
 #endif
-constexpr uint32_t kShadeThreshold = PTX_SHADE_THRESHOLD;
 
 constexpr int kModeCounts = 0;    // `-a`: gpuRender.cu:146-150
 constexpr int kModeRadiance = 1;  // gpuRender.cu:132-169
@@ -113,11 +114,9 @@ __global__ void __launch_bounds__(kBlockThreads) pathKernel(DeviceScene sc, Fram
   const vec3 camPos(fc.camPos[0], fc.camPos[1], fc.camPos[2]);
 
   // ---- lane state ----
-  uint32_t ref = kRefDone;   // node reference the lane processes next
-  bool exhausted = false;    // no more pixels for this lane
+  uint32_t ref = kRefDone;   // what the lane does next (see the table above)
   bool pending = false;      // a traced ray's result waits for the shading phase
   bool havePixel = false;
-  bool inBlas = false;
   bool zeroDir = false;      // a component of the current ray's direction is exactly 0 (0*inf possible)
   uint32_t pix = 0, sample = 0, bounce = 0, rng = 0, count = 0;
   uint32_t tlasLeaf = 0, curInst = 0;
@@ -134,11 +133,11 @@ __global__ void __launch_bounds__(kBlockThreads) pathKernel(DeviceScene sc, Fram
 
   for (;;) {
     // =========================== shading phase (postponed, wave-wide) ===========================
-    const bool waiting = !exhausted && ref == kRefDone;
+    const bool waiting = ref == kRefDone;
     const uint32_t nWaiting = (uint32_t)__popcll(__ballot(waiting));
-    const uint32_t nLive = (uint32_t)__popcll(__ballot(!exhausted));
+    const uint32_t nLive = 64u - (uint32_t)__popcll(__ballot(ref == kRefIdle));
     if (nLive == 0u) break;
-    if (nWaiting >= kShadeThreshold || nWaiting * 4u >= nLive) {
+    if (nWaiting >= PTX_SHADE_THRESHOLD || nWaiting * 4u >= nLive) {
       if (waiting) {
         bool pathEnded = true;
         if (pending) {
@@ -163,10 +162,11 @@ __global__ void __launch_bounds__(kBlockThreads) pathKernel(DeviceScene sc, Fram
             sample++;
           }
         }
+        bool live = true;
         if (pathEnded) {
           // ---- pixel finished? write it and pull the next one ----
           const uint32_t perPixel = (MODE == kModeCounts) ? 1u : fc.spp;
-          while (sample >= perPixel && !exhausted) {
+          while (sample >= perPixel && live) {
             if (MODE == kModeRadiance && havePixel) {
               if (RESOLVE) {
                 const vec3 c = resolvePixel(sum, (float)fc.spp);
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(kBlockThreads) pathKernel(DeviceScene sc, Fram
             }
             const uint32_t w = atomicAdd(workCounter, 1u);  // aggregated per wave by the compiler
             if (w >= totalWork) {
-              exhausted = true;
+              live = false;
               havePixel = false;
               break;
             }
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(kBlockThreads) pathKernel(DeviceScene sc, Fram
               sample = fc.spp;
             }
           }
-          if (!exhausted) {
+          if (live) {
             // ---- next camera ray: gpuRender.cu:132-143 ----
             const uint32_t py = pix / fc.width, px = pix - py * fc.width;
             float fx = (float)px, fy = (float)py;
@@ -220,118 +220,120 @@ __global__ void __launch_bounds__(kBlockThreads) pathKernel(DeviceScene sc, Fram
             if (MODE == kModeCounts) sample = 1u;  // one ray per pixel
           }
         }
-        if (!exhausted) {
+        if (live) {
           // ---- launch the segment: Scene::intersect starts at the TLAS root ----
           winv = 1.0f / wd;
           o = wo; d = wd; inv = winv;
           zeroDir = (wd.x == 0.0f) || (wd.y == 0.0f) || (wd.z == 0.0f);
           hit.t = FLT_MAX; hit.u = 0.0f; hit.v = 0.0f; hit.tri = 0xFFFFFFFFu; hit.inst = 0xFFFFFFFFu;
           count = 0u;
-          inBlas = false;
           tlasLeaf = 0u;
-          sStack[threadIdx.x] = kRefDone;  // slot 0: bottom-of-stack marker
+          stk.lds[0] = kRefDone;  // slot 0: bottom-of-stack marker
           sp = 1u;
           ref = sc.tlasRootRef;
           pending = true;
+        } else {
+          ref = kRefIdle;
         }
       }
     }
 
-    // ================================ one traversal step per lane ================================
-    // Every lane is in exactly one state.  All lanes first issue the same three memory operations --
-    // the LDS read of their stack top and ONE 64-byte fetch of the record their state needs (NodePair,
-    // TriRec or InstXform, all in one arena) -- so an iteration pays one memory latency, not one per
-    // state; the state bodies then run from registers, predicated, without further loads.
-    const bool active = !exhausted && ref != kRefDone;
-    const bool isExit = active && ref == kRefInstExit;
-    const bool isLeaf = active && !isExit && (ref & kLeafFlag) != 0u;
-    const bool isEnter = isLeaf && !inBlas;
-    const bool isTri = isLeaf && inBlas;
-    const bool isNode = active && (ref & kLeafFlag) == 0u;
-    const uint32_t first = ref & 0x00FFFFFFu;
-    const uint32_t nPrim = ((ref >> 24) & 0x7Fu) + 1u;
+    // ============================== traversal steps, one per lane each ===============================
+#pragma unroll 1
+    for (int it = 0; it < PTX_INNER_ITERS; it++) {
+      const bool isNode = (int32_t)ref >= 0;
+      const bool isSpecial = ref >= kRefIdle;  // idle / done / instance exit
+      const bool isExit = ref == kRefInstExit;
+      const bool isTri = (ref >> 30) == 2u;
+      bool isEnter = (ref >> 30) == 3u && !isSpecial;
+      if (PTX_ENTER_THRESHOLD > 1) {
+        // the instance-entry body is long and rarely needed: run it when a few lanes want it, or when
+        // nothing else is left to do in this wave
+        const uint32_t nEnter = (uint32_t)__popcll(__ballot(isEnter));
+        if (nEnter < PTX_ENTER_THRESHOLD && __any(isNode || isTri)) isEnter = false;
+      }
+      const bool steps = isNode || isTri || isEnter || isExit;
+      const uint32_t first = ref & (isTri ? 0x007FFFFFu : 0x00FFFFFFu);
+      const uint32_t nPrim = (isTri ? ((ref >> 23) & 0x7Fu) : ((ref >> 24) & 0x3Fu)) + 1u;
 
-    const bool deep = __any(sp + 2u >= kLdsStack);  // wave-uniform; false almost always
-    const uint32_t top = stackRead(stk, sp ? sp - 1u : 0u, deep);
+      const bool deep = __any(sp + 2u >= kLdsStack);  // wave-uniform; false almost always
+      const uint32_t top = stackRead(stk, sp ? sp - 1u : 0u, deep);
 
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
-    if (active && !isExit) {
-      // record address in 16-byte units from the arena base
-      const uint32_t off16 = isNode ? sc.pairs16 + ref * 4u : (isTri ? sc.tris16 + first * 3u : sc.inst16 + first * 4u);
+      // record address in 16-byte units from the arena base; lanes with nothing to fetch read the
+      // first record of the arena (same line for all of them) so that the loads need no predication
+      const uint32_t off16 = isNode ? sc.pairs16 + ref * 4u : (isTri ? sc.tris16 + first * 3u : (isEnter ? sc.inst16 + first * 4u : 0u));
       const float4* rp = sc.arena + off16;
-      r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3];
-    }
+      const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
 
-    uint32_t newRef = ref;
-    uint32_t pushVal = 0u;
-    bool doPush = false, doPop = false;
+      uint32_t newRef = ref;
+      uint32_t pushVal = 0u;
+      bool doPush = false, doPop = false;
 
-    if (isExit) {
-      // GPUMesh::intersect returns (ray.t = transformedRay.t); intersectTLAS keeps the instance if it
-      // lowered t (intersection.hpp:184-189).
-      if (hit.t < tBeforeInst) hit.inst = curInst;
-      o = wo; d = wd; inv = winv;
-      zeroDir = (wd.x == 0.0f) || (wd.y == 0.0f) || (wd.z == 0.0f);
-      inBlas = false;
-      doPop = tlasLeaf == 0u;
-      newRef = doPop ? top : tlasLeaf;
-      tlasLeaf = 0u;
-    }
-    if (isEnter) {
-      // TLAS leaf: enter its first instance, keep the rest of the leaf (gpuFunctions.hpp:32-41).
-      tlasLeaf = (nPrim > 1u) ? makeLeafRef(first + 1u, nPrim - 1u) : 0u;
-      curInst = first;
-      o = xformRows(r0, r1, r2, wo, 1.0f);
-      d = xformRows(r0, r1, r2, wd, 0.0f);  // not normalised: t stays world-space
-      inv = 1.0f / d;
-      zeroDir = (d.x == 0.0f) || (d.y == 0.0f) || (d.z == 0.0f);
-      tBeforeInst = hit.t;
-      inBlas = true;
-      if (STATS) nInstEntries++;
-      pushVal = kRefInstExit;
-      doPush = true;
-      newRef = __float_as_uint(r3.x);  // InstXform::rootRef
-    }
-    if (isTri) {
-      // BLAS leaf, one triangle per step, in order, strict `<` (intersection.hpp:9-44, :112-122).
-      TriRec tri;
-      tri.v0 = r0; tri.e1 = r1; tri.e2 = r2;
-      float u = 0.0f, v = 0.0f;
-      const float dist = triangleTest(o, d, tri, u, v);
-      if (dist < hit.t) {
-        hit.t = dist; hit.u = u; hit.v = v; hit.tri = first;
+      if (isExit) {
+        // GPUMesh::intersect returns (ray.t = transformedRay.t); intersectTLAS keeps the instance if it
+        // lowered t (intersection.hpp:184-189).
+        if (hit.t < tBeforeInst) hit.inst = curInst;
+        o = wo; d = wd; inv = winv;
+        zeroDir = (wd.x == 0.0f) || (wd.y == 0.0f) || (wd.z == 0.0f);
+        doPop = tlasLeaf == 0u;
+        newRef = doPop ? top : tlasLeaf;
+        tlasLeaf = 0u;
       }
-      if (STATS) nTriTests++;
-      doPop = nPrim == 1u;
-      newRef = doPop ? top : makeLeafRef(first + 1u, nPrim - 1u);
-    }
-    if (isNode) {
-      // Internal node (intersection.hpp:133-161 / :201-230): one 64-byte record holds both children.
-      float d1, d2;
-      if (__any(zeroDir)) {
-        d1 = slabTest<true>(o, inv, hit.t, r0, r1);
-        d2 = slabTest<true>(o, inv, hit.t, r2, r3);
-      } else {
-        d1 = slabTest<false>(o, inv, hit.t, r0, r1);
-        d2 = slabTest<false>(o, inv, hit.t, r2, r3);
+      if (isEnter) {
+        // TLAS leaf: enter its first instance, keep the rest of the leaf (gpuFunctions.hpp:32-41).
+        tlasLeaf = (nPrim > 1u) ? makeTlasLeafRef(first + 1u, nPrim - 1u) : 0u;
+        curInst = first;
+        o = xformRows(r0, r1, r2, wo, 1.0f);
+        d = xformRows(r0, r1, r2, wd, 0.0f);  // not normalised: t stays world-space
+        inv = 1.0f / d;
+        zeroDir = (d.x == 0.0f) || (d.y == 0.0f) || (d.z == 0.0f);
+        tBeforeInst = hit.t;
+        if (STATS) nInstEntries++;
+        pushVal = kRefInstExit;
+        doPush = true;
+        newRef = __float_as_uint(r3.x);  // InstXform::rootRef
       }
-      const uint32_t rl = __float_as_uint(r0.w), rr = __float_as_uint(r2.w);
-      if (STATS) nNodeSteps++;
-      const bool swap = d1 > d2;  // nearer child first; ties keep the left child
-      const float dn = swap ? d2 : d1, df = swap ? d1 : d2;
-      const uint32_t rn = swap ? rr : rl, rf = swap ? rl : rr;
-      const bool hitNear = dn != FLT_MAX, hitFar = df != FLT_MAX;  // far hit implies near hit
-      count += (hitNear ? 1u : 0u) + (hitFar ? 1u : 0u);  // counted when pushed, not re-tested when popped
-      pushVal = rf;
-      doPush = hitFar;
-      doPop = !hitNear;
-      newRef = hitNear ? rn : top;
-    }
+      if (isTri) {
+        // BLAS leaf, one triangle per step, in order, strict `<` (intersection.hpp:9-44, :112-122).
+        TriRec tri;
+        tri.v0 = r0; tri.e1 = r1; tri.e2 = r2;
+        float u = 0.0f, v = 0.0f;
+        const float dist = triangleTest(o, d, tri, u, v);
+        if (dist < hit.t) {
+          hit.t = dist; hit.u = u; hit.v = v; hit.tri = first;
+        }
+        if (STATS) nTriTests++;
+        doPop = nPrim == 1u;
+        newRef = doPop ? top : makeLeafRef(first + 1u, nPrim - 1u);
+      }
+      if (isNode) {
+        // Internal node (intersection.hpp:133-161 / :201-230): one 64-byte record holds both children.
+        float d1, d2;
+        if (__any(zeroDir)) {
+          d1 = slabTest<true>(o, inv, hit.t, r0, r1);
+          d2 = slabTest<true>(o, inv, hit.t, r2, r3);
+        } else {
+          d1 = slabTest<false>(o, inv, hit.t, r0, r1);
+          d2 = slabTest<false>(o, inv, hit.t, r2, r3);
+        }
+        const uint32_t rl = __float_as_uint(r0.w), rr = __float_as_uint(r2.w);
+        if (STATS) nNodeSteps++;
+        const bool swap = d1 > d2;  // nearer child first; ties keep the left child
+        const float dn = swap ? d2 : d1, df = swap ? d1 : d2;
+        const uint32_t rn = swap ? rr : rl, rf = swap ? rl : rr;
+        const bool hitNear = dn != FLT_MAX, hitFar = df != FLT_MAX;  // far hit implies near hit
+        count += (hitNear ? 1u : 0u) + (hitFar ? 1u : 0u);  // counted when pushed, not re-tested when popped
+        pushVal = rf;
+        doPush = hitFar;
+        doPop = !hitNear;
+        newRef = hitNear ? rn : top;
+      }
 
-    if (active) {
-      stackWrite(stk, sp, pushVal, deep);
-      sp = sp + (doPush ? 1u : 0u) - (doPop ? 1u : 0u);
-      ref = newRef;
+      if (steps) {
+        stackWrite(stk, sp, pushVal, deep);
+        sp = sp + (doPush ? 1u : 0u) - (doPop ? 1u : 0u);
+        ref = newRef;
+      }
     }
   }
 

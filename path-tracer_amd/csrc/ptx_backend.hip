@@ -43,8 +43,9 @@ struct TreeInfo {
 
 // Converts one reference-layout tree (32-byte nodes, children adjacent at left_first, left_first+1)
 // into NodePair records appended to `pairs`.  primBase is added to leaf primitive indices.
-int convertTree(const ptx_bvh_node* nodes, uint32_t n, uint32_t primBase, uint32_t primCount, const char* what,
+int convertTree(const ptx_bvh_node* nodes, uint32_t n, uint32_t primBase, uint32_t primCount, bool isTlas,
                 std::vector<NodePair>& pairs, TreeInfo& info) {
+  const char* what = isTlas ? "TLAS" : "BLAS";
   if (n == 0 || (n & 1u) == 0u) return fail(PTX_EINVAL, std::string(what) + ": node count must be odd and > 0");
   const uint32_t pairBase = (uint32_t)pairs.size();
   const uint32_t nPairs = (n - 1u) / 2u;
@@ -53,10 +54,12 @@ int convertTree(const ptx_bvh_node* nodes, uint32_t n, uint32_t primBase, uint32
 
   auto makeRef = [&](const ptx_bvh_node& nd, uint32_t& ref) -> int {
     if (nd.count > 0) {
-      if (nd.count > kMaxLeafPrims) return fail(PTX_ELIMIT, std::string(what) + ": a leaf holds more than 128 primitives");
+      if (nd.count > (isTlas ? kMaxTlasLeafPrims : kMaxBlasLeafPrims))
+        return fail(PTX_ELIMIT, std::string(what) + ": a leaf holds more primitives than a node reference can encode (128 triangles / 64 instances)");
       if ((uint64_t)nd.left_first + nd.count > primCount) return fail(PTX_EINVAL, std::string(what) + ": leaf range outside the primitive array");
-      if ((uint64_t)primBase + nd.left_first + nd.count > kMaxPrimIndex) return fail(PTX_ELIMIT, "primitive index exceeds 24 bits");
-      ref = makeLeafRef(primBase + nd.left_first, nd.count);
+      if ((uint64_t)primBase + nd.left_first + nd.count > (isTlas ? kMaxInstIndex : kMaxTriIndex))
+        return fail(PTX_ELIMIT, "primitive index exceeds what a node reference can encode (2^23 triangles / 2^24 instances)");
+      ref = isTlas ? makeTlasLeafRef(primBase + nd.left_first, nd.count) : makeLeafRef(primBase + nd.left_first, nd.count);
     } else {
       if ((nd.left_first & 1u) == 0u || (uint64_t)nd.left_first + 1u >= n)
         return fail(PTX_EINVAL, std::string(what) + ": child index not of the form 2k+1 / out of range");
@@ -295,7 +298,7 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
   // ---- host re-layout ----
   std::vector<NodePair> pairs;
   TreeInfo tlas;
-  int rc = convertTree(d->tlas_nodes, d->tlas_node_count, 0u, d->instance_count, "TLAS", pairs, tlas);
+  int rc = convertTree(d->tlas_nodes, d->tlas_node_count, 0u, d->instance_count, true, pairs, tlas);
   if (rc) return rc;
 
   std::vector<TreeInfo> blas(d->geometry_count);
@@ -310,7 +313,7 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
       return fail(PTX_EINVAL, "vertex normal range outside the array");
     if (G.vtx_uv_offset != PTX_NONE && (!d->vtx_uvs || (uint64_t)G.vtx_uv_offset + 3ull * G.tri_count > d->vtx_uv_total))
       return fail(PTX_EINVAL, "uv range outside the array");
-    rc = convertTree(d->blas_nodes + G.node_offset, G.node_count, G.tri_offset, G.tri_count, "BLAS", pairs, blas[g]);
+    rc = convertTree(d->blas_nodes + G.node_offset, G.node_count, G.tri_offset, G.tri_count, false, pairs, blas[g]);
     if (rc) return rc;
     if (blas[g].depth > blasDepth) blasDepth = blas[g].depth;
     geomShade[g].triBase = G.tri_offset;
