@@ -37,7 +37,13 @@
 namespace ptx {
 
 constexpr uint32_t kBlockThreads = 256;  // 4 waves
-constexpr uint32_t kLdsStack = 24;       // stack entries per lane kept in LDS (24 KB per block)
+#ifndef PTX_LDS_STACK
+#define PTX_LDS_STACK 24
+#endif
+#ifndef PTX_MIN_WAVES
+#define PTX_MIN_WAVES 5
+#endif
+constexpr uint32_t kLdsStack = PTX_LDS_STACK;  // stack entries per lane kept in LDS (1 KB per entry per block)
 // Tunables (see DESIGN.md "Scheduling inside a wave").
 #ifndef PTX_SHADE_THRESHOLD
 #define PTX_SHADE_THRESHOLD 12  // waiting lanes that trigger the shading phase
@@ -100,7 +106,7 @@ __device__ __forceinline__ void workPixel(const FrameConstants& fc, uint32_t w, 
 }
 
 template <int MODE, bool STATS, bool RESOLVE>
-__global__ void __launch_bounds__(kBlockThreads) pathKernel(DeviceScene sc, FrameConstants fc, uint32_t* workCounter,
+__global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(DeviceScene sc, FrameConstants fc, uint32_t* workCounter,
                                                             void* __restrict__ outRaw, DeviceStats* stats,
                                                             uint32_t* stackOverflow) {
   __shared__ uint32_t sStack[kLdsStack * kBlockThreads];
