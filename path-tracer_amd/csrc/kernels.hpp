@@ -55,6 +55,13 @@ constexpr uint32_t kLdsStack = PTX_LDS_STACK;  // stack entries per lane kept in
 #define PTX_INNER_ITERS 1       // traversal iterations between two checks for the shading phase
 #endif
 
+// Optional markers in the generated assembly (tools/count_isa.py); no code is emitted for them.
+#ifdef PTX_ISA_MARKERS
+#define PTX_MARK(name) asm volatile("; PTXMARK " name)
+#else
+#define PTX_MARK(name) do {} while (0)
+#endif
+
 constexpr int kModeCounts = 0;    // `-a`: gpuRender.cu:146-150
 constexpr int kModeRadiance = 1;  // gpuRender.cu:132-169
 
@@ -247,6 +254,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
     // ============================== traversal steps, one per lane each ===============================
 #pragma unroll 1
     for (int it = 0; it < PTX_INNER_ITERS; it++) {
+      PTX_MARK("TRAV_BEGIN");
       const bool isNode = (int32_t)ref >= 0;
       const bool isSpecial = ref >= kRefIdle;  // idle / done / instance exit
       const bool isExit = ref == kRefInstExit;
@@ -275,6 +283,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       uint32_t pushVal = 0u;
       bool doPush = false, doPop = false;
 
+      PTX_MARK("EXIT");
       if (isExit) {
         // GPUMesh::intersect returns (ray.t = transformedRay.t); intersectTLAS keeps the instance if it
         // lowered t (intersection.hpp:184-189).
@@ -285,6 +294,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
         newRef = doPop ? top : tlasLeaf;
         tlasLeaf = 0u;
       }
+      PTX_MARK("ENTER");
       if (isEnter) {
         // TLAS leaf: enter its first instance, keep the rest of the leaf (gpuFunctions.hpp:32-41).
         tlasLeaf = (nPrim > 1u) ? makeTlasLeafRef(first + 1u, nPrim - 1u) : 0u;
@@ -299,6 +309,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
         doPush = true;
         newRef = __float_as_uint(r3.x);  // InstXform::rootRef
       }
+      PTX_MARK("TRI");
       if (isTri) {
         // BLAS leaf, one triangle per step, in order, strict `<` (intersection.hpp:9-44, :112-122).
         TriRec tri;
@@ -312,6 +323,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
         doPop = nPrim == 1u;
         newRef = doPop ? top : makeLeafRef(first + 1u, nPrim - 1u);
       }
+      PTX_MARK("NODE");
       if (isNode) {
         // Internal node (intersection.hpp:133-161 / :201-230): one 64-byte record holds both children.
         float d1, d2;
@@ -335,11 +347,13 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
         newRef = hitNear ? rn : top;
       }
 
+      PTX_MARK("MERGE");
       if (steps) {
         stackWrite(stk, sp, pushVal, deep);
         sp = sp + (doPush ? 1u : 0u) - (doPop ? 1u : 0u);
         ref = newRef;
       }
+      PTX_MARK("TRAV_END");
     }
   }
 
