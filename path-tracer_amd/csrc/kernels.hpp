@@ -51,6 +51,9 @@ constexpr uint32_t kLdsStack = PTX_LDS_STACK;  // stack entries per lane kept in
 #ifndef PTX_ENTER_THRESHOLD
 #define PTX_ENTER_THRESHOLD 1   // lanes at a TLAS leaf before the (rare, long) instance-entry body is run
 #endif
+#ifndef PTX_RARE_PERIOD
+#define PTX_RARE_PERIOD 1      // run the instance entry / exit bodies on every n-th iteration only
+#endif
 #ifndef PTX_INNER_ITERS
 #define PTX_INNER_ITERS 1       // traversal iterations between two checks for the shading phase
 #endif
@@ -144,7 +147,9 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
   uint32_t nRays = 0, nNodeSteps = 0, nTriTests = 0, nInstEntries = 0, nHits = 0, nMisses = 0;
   unsigned long long nBoxHits = 0;
 
+  uint32_t loopCount = 0;
   for (;;) {
+    loopCount++;
     // =========================== shading phase (postponed, wave-wide) ===========================
     const bool waiting = ref == kRefDone;
     const uint32_t nWaiting = (uint32_t)__popcll(__ballot(waiting));
@@ -257,7 +262,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       PTX_MARK("TRAV_BEGIN");
       const bool isNode = (int32_t)ref >= 0;
       const bool isSpecial = ref >= kRefIdle;  // idle / done / instance exit
-      const bool isExit = ref == kRefInstExit;
+      bool isExit = ref == kRefInstExit;
       const bool isTri = (ref >> 30) == 2u;
       bool isEnter = (ref >> 30) == 3u && !isSpecial;
       if (PTX_ENTER_THRESHOLD > 1) {
@@ -265,6 +270,14 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
         // nothing else is left to do in this wave
         const uint32_t nEnter = (uint32_t)__popcll(__ballot(isEnter));
         if (nEnter < PTX_ENTER_THRESHOLD && __any(isNode || isTri)) isEnter = false;
+      }
+      if (PTX_RARE_PERIOD > 1) {
+        // instance entry / exit bodies run on every PTX_RARE_PERIOD-th iteration only (a lane waits at
+        // most PTX_RARE_PERIOD - 1 iterations for them), unless no lane has anything else to do
+        if ((loopCount % PTX_RARE_PERIOD) != 0u && __any(isNode || isTri)) {
+          isEnter = false;
+          isExit = false;
+        }
       }
       const bool steps = isNode || isTri || isEnter || isExit;
       const uint32_t first = ref & (isTri ? 0x007FFFFFu : 0x00FFFFFFu);
