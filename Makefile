@@ -11,7 +11,7 @@ HIPCC    = /opt/rocm/bin/hipcc
 # -ffp-contract=off everywhere: the BVH, the instance matrices and the -a heat map are bit-exact
 # contracts between x86-64 and gfx950 (DESIGN.md "Floating point").
 CXXFLAGS = -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra -Iinclude
-HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Iinclude \
+HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Iinclude \
            -fhip-fp32-correctly-rounded-divide-sqrt
 
 HOST_SRC = $(HOST)/scene.cpp $(HOST)/loaders.cpp $(HOST)/sample_scenes.cpp $(HOST)/flatten.cpp \

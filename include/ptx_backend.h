@@ -134,7 +134,13 @@ typedef struct ptx_params {
   uint32_t part_count;   /*   counts: 8x8 tiles with (tile % part_count) == part_index, other pixels
                               are written as 0;  radiance: RNG stream id (sample-slice split).
                               part_count <= 1 means the whole frame. */
-  uint32_t reserved;
+  uint32_t sub_streams;  /* radiance, PTX_SEED_STREAM only: split this call's spp over this many RNG streams
+                              per pixel (stream id = part_index * sub_streams + k, k-th stream gets
+                              spp / sub_streams samples, the first spp % sub_streams one more), each a
+                              separate work item; partial sums are added in stream order.  The reference
+                              has one serial stream per pixel, i.e. W*H independent chains; a chip with
+                              more lanes than that idles through the tail of every frame.  0 or 1 = one
+                              stream (required for PTX_SEED_REFERENCE_GPU); at most 256. */
 } ptx_params;
 
 typedef struct ptx_stats {

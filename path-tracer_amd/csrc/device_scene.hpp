@@ -121,6 +121,8 @@ struct FrameConstants {
   uint32_t seedBase;    // 1023u (+ stream offset)
   uint32_t partIndex, partCount;
   uint32_t tilesX, tilesY;
+  uint32_t subStreams;          // RNG streams per pixel in this launch (>= 1), each a separate work item
+  uint32_t sppBase, sppExtra;   // stream k renders sppBase + (k < sppExtra) samples
 };
 
 struct DeviceStats {  // accumulated with atomics by the instrumented kernel variants

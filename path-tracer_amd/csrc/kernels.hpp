@@ -65,8 +65,19 @@ constexpr uint32_t kLdsStack = PTX_LDS_STACK;  // stack entries per lane kept in
 #define PTX_MARK(name) do {} while (0)
 #endif
 
+// Wave-level execution profile of the main loop (profiling builds only: -DPTX_WAVE_PROFILE; filled by the
+// STATS instantiations, read with ptx_debug_wave_profile).  [2k] = iterations in which body k ran,
+// [2k+1] = lanes that were active in it.
+#ifdef PTX_WAVE_PROFILE
+__device__ unsigned long long gWaveProfile[32];
+#define PTX_PROF(k, lanes) do { if (STATS) { prof[2 * (k)] += 1u; prof[2 * (k) + 1] += (uint32_t)__popcll(__ballot(lanes)); } } while (0)
+#else
+#define PTX_PROF(k, lanes) do {} while (0)
+#endif
+
 constexpr int kModeCounts = 0;    // `-a`: gpuRender.cu:146-150
 constexpr int kModeRadiance = 1;  // gpuRender.cu:132-169
+constexpr int kModeCost = 2;      // scheduling pre-pass: primary ray only, writes a per-pixel cost estimate
 
 // Per-lane traversal stack: entries [0, kLdsStack) live in LDS as sStack[entry][thread] (consecutive
 // lanes -> consecutive banks); deeper entries go to a per-launch global overflow buffer laid out
@@ -105,7 +116,17 @@ __device__ __forceinline__ void stackWrite(const StackMem& m, uint32_t slot, uin
 // Work item -> pixel.  The image is cut into bands of 8 rows; inside a band items run down a column
 // first, so 64 consecutive items (one wave's first fetch) form an 8x8 block of adjacent pixels for
 // any image size, with no padding items.
-__device__ __forceinline__ void workPixel(const FrameConstants& fc, uint32_t w, uint32_t& x, uint32_t& y) {
+__device__ __forceinline__ bool workPixel(const FrameConstants& fc, const uint32_t* __restrict__ tileOrder, uint32_t w, uint32_t& x,
+                                          uint32_t& y) {
+  if (tileOrder) {
+    // cost-ordered schedule: 64 consecutive items = one 8x8 tile, tiles in the order of the pre-pass
+    // (most expensive first); items of an edge tile that fall outside the image are skipped
+    const uint32_t t = tileOrder[w >> 6], i = w & 63u;
+    const uint32_t ty = t / fc.tilesX, tx = t - ty * fc.tilesX;
+    x = tx * 8u + (i >> 3);
+    y = ty * 8u + (i & 7u);
+    return x < fc.width && y < fc.height;
+  }
   const uint32_t bandItems = fc.width * 8u;
   const uint32_t band = w / bandItems;
   const uint32_t r = w - band * bandItems;
@@ -113,12 +134,14 @@ __device__ __forceinline__ void workPixel(const FrameConstants& fc, uint32_t w, 
   const uint32_t cx = r / rows;
   x = cx;
   y = band * 8u + (r - cx * rows);
+  return true;
 }
 
 template <int MODE, bool STATS, bool RESOLVE>
 __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(DeviceScene sc, FrameConstants fc, uint32_t* workCounter,
                                                             void* __restrict__ outRaw, DeviceStats* stats,
-                                                            uint32_t* stackOverflow) {
+                                                            uint32_t* stackOverflow, const uint32_t* __restrict__ tileOrder) {
+  constexpr bool kOneRay = MODE != kModeRadiance;  // heat map / cost pre-pass: one primary ray per pixel
   __shared__ uint32_t sStack[kLdsStack * kBlockThreads];
   StackMem stk;
   stk.lds = sStack + threadIdx.x;
@@ -126,7 +149,9 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
   stk.stride = gridDim.x * kBlockThreads;
   uint32_t sp = 1;
 
-  const uint32_t totalWork = fc.width * fc.height;
+  const uint32_t nPixels = fc.width * fc.height;
+  const uint32_t itemsPerStream = tileOrder ? fc.tilesX * fc.tilesY * 64u : nPixels;
+  const uint32_t totalWork = itemsPerStream * fc.subStreams;  // checked on the host to fit 32 bits
   const vec3 camPos(fc.camPos[0], fc.camPos[1], fc.camPos[2]);
 
   // ---- lane state ----
@@ -134,7 +159,9 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
   bool pending = false;      // a traced ray's result waits for the shading phase
   bool havePixel = false;
   bool zeroDir = false;      // a component of the current ray's direction is exactly 0 (0*inf possible)
-  uint32_t pix = 0, sample = 0, bounce = 0, rng = 0, count = 0;
+  uint32_t pix = 0;     // pixel index (bits 0..23) | RNG stream of this item (bits 24..31)
+  uint32_t sample = 0;  // samples (rays, for the one-ray modes) this item still has to do; 0 = pull the next item
+  uint32_t bounce = 0, rng = 0, count = 0;
   uint32_t tlasLeaf = 0, curInst = 0;
   float tBeforeInst = FLT_MAX;
   vec3 sum(0.0f), col(1.0f);
@@ -142,11 +169,13 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
   vec3 o(0.0f), d(0.0f, 0.0f, -1.0f), inv(0.0f);     // current ray (world or object space)
   Hit hit;
   hit.t = FLT_MAX; hit.u = 0.0f; hit.v = 0.0f; hit.tri = 0xFFFFFFFFu; hit.inst = 0xFFFFFFFFu;
-  sample = (MODE == kModeCounts) ? 1u : fc.spp;  // "pixel finished": the first shading phase pulls work
 
   uint32_t nRays = 0, nNodeSteps = 0, nTriTests = 0, nInstEntries = 0, nHits = 0, nMisses = 0;
   unsigned long long nBoxHits = 0;
 
+#ifdef PTX_WAVE_PROFILE
+  unsigned long long prof[16] = {};
+#endif
   uint32_t loopCount = 0;
   for (;;) {
     loopCount++;
@@ -155,7 +184,9 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
     const uint32_t nWaiting = (uint32_t)__popcll(__ballot(waiting));
     const uint32_t nLive = 64u - (uint32_t)__popcll(__ballot(ref == kRefIdle));
     if (nLive == 0u) break;
+    PTX_PROF(0, ref != kRefIdle);
     if (nWaiting >= PTX_SHADE_THRESHOLD || nWaiting * 4u >= nLive) {
+      PTX_PROF(1, waiting);
       if (waiting) {
         bool pathEnded = true;
         if (pending) {
@@ -164,8 +195,13 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
             nRays++;
             nBoxHits += count;
           }
+          if (kOneRay) sample = 0u;
           if (MODE == kModeCounts) {
             reinterpret_cast<uint32_t*>(outRaw)[pix] = count;
+          } else if (MODE == kModeCost) {
+            // a pixel whose primary ray hits geometry goes on bouncing inside the scene; one that
+            // leaves it ends after one ray per sample
+            reinterpret_cast<uint32_t*>(outRaw)[pix] = (hit.t < FLT_MAX) ? 8u * count + 64u : count + 1u;
           } else if (hit.t < FLT_MAX) {
             if (STATS) nHits++;
             shadeHit(sc, hit, wo, wd, rng, col);  // writes the next ray into wo / wd
@@ -177,23 +213,24 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
           }
           if (MODE == kModeRadiance && pathEnded) {
             sum += col;
-            sample++;
+            sample--;
           }
         }
         bool live = true;
         if (pathEnded) {
-          // ---- pixel finished? write it and pull the next one ----
-          const uint32_t perPixel = (MODE == kModeCounts) ? 1u : fc.spp;
-          while (sample >= perPixel && live) {
+          // ---- item finished? write it and pull the next one ----
+          while (sample == 0u && live) {
             if (MODE == kModeRadiance && havePixel) {
-              if (RESOLVE) {
+              const uint32_t p = pix & 0x00FFFFFFu, k = pix >> 24;
+              if (RESOLVE) {  // one stream per pixel (host-checked)
                 const vec3 c = resolvePixel(sum, (float)fc.spp);
                 float* out = reinterpret_cast<float*>(outRaw);
-                out[3ull * pix + 0] = c.x;
-                out[3ull * pix + 1] = c.y;
-                out[3ull * pix + 2] = c.z;
-              } else {
-                reinterpret_cast<float4*>(outRaw)[pix] = make_float4(sum.x, sum.y, sum.z, (float)fc.spp);
+                out[3ull * p + 0] = c.x;
+                out[3ull * p + 1] = c.y;
+                out[3ull * p + 2] = c.z;
+              } else {  // plane k of the accumulation buffer: (sum, samples) of stream k
+                const uint32_t n = fc.sppBase + (k < fc.sppExtra ? 1u : 0u);
+                reinterpret_cast<float4*>(outRaw)[(size_t)k * nPixels + p] = make_float4(sum.x, sum.y, sum.z, (float)n);
               }
             }
             const uint32_t w = atomicAdd(workCounter, 1u);  // aggregated per wave by the compiler
@@ -202,29 +239,35 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
               havePixel = false;
               break;
             }
+            const uint32_t k = fc.subStreams > 1u ? w / itemsPerStream : 0u;
             uint32_t x, y;
-            workPixel(fc, w, x, y);
-            pix = y * fc.width + x;
+            if (!workPixel(fc, tileOrder, w - k * itemsPerStream, x, y)) {
+              havePixel = false;
+              continue;  // outside the image (edge tile): pull the next item
+            }
+            const uint32_t p = y * fc.width + x;
+            pix = p | (k << 24);
             sum = vec3(0.0f);
-            rng = fc.seedBase + pix;  // gpuRender.cu:130
+            rng = fc.seedBase + p + k * 0x9E3779B9u;  // gpuRender.cu:130 (+ stream offset)
             havePixel = true;
-            sample = 0u;
-            if (MODE == kModeCounts) {
-              if (fc.partCount > 1u) {
+            sample = kOneRay ? 1u : fc.sppBase + (k < fc.sppExtra ? 1u : 0u);
+            if (kOneRay) {
+              if (MODE == kModeCounts && fc.partCount > 1u) {
                 const uint32_t tile = (y >> 3) * fc.tilesX + (x >> 3);
                 if ((tile % fc.partCount) != fc.partIndex) {
-                  reinterpret_cast<uint32_t*>(outRaw)[pix] = 0u;
-                  sample = 1u;  // not this part's tile: finished
+                  reinterpret_cast<uint32_t*>(outRaw)[p] = 0u;
+                  sample = 0u;  // not this part's tile: finished
                 }
               }
             } else if (fc.maxBounces == 0u) {
-              sum = vec3((float)fc.spp);  // no segment is traced: every path returns white (gpuRender.cu:27-29)
-              sample = fc.spp;
+              sum = vec3((float)sample);  // no segment is traced: every path returns white (gpuRender.cu:27-29)
+              sample = 0u;
             }
           }
           if (live) {
             // ---- next camera ray: gpuRender.cu:132-143 ----
-            const uint32_t py = pix / fc.width, px = pix - py * fc.width;
+            const uint32_t p = pix & 0x00FFFFFFu;
+            const uint32_t py = p / fc.width, px = p - py * fc.width;
             float fx = (float)px, fy = (float)py;
             if (MODE == kModeRadiance && fc.spp > 1u) {
               const vec2 xi = pt::getRandomVec2(rng);
@@ -235,7 +278,6 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
             wd = primaryDirection(fc, fx, fy);
             col = vec3(1.0f);
             bounce = 0u;
-            if (MODE == kModeCounts) sample = 1u;  // one ray per pixel
           }
         }
         if (live) {
@@ -296,6 +338,12 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       uint32_t pushVal = 0u;
       bool doPush = false, doPop = false;
 
+      PTX_PROF(2, steps);
+      if (__any(isExit)) PTX_PROF(3, isExit);
+      if (__any(isEnter)) PTX_PROF(4, isEnter);
+      if (__any(isTri)) PTX_PROF(5, isTri);
+      if (__any(isNode)) PTX_PROF(6, isNode);
+      if (__any(isNode) && __any(zeroDir)) PTX_PROF(7, isNode);
       PTX_MARK("EXIT");
       if (isExit) {
         // GPUMesh::intersect returns (ray.t = transformedRay.t); intersectTLAS keeps the instance if it
@@ -370,6 +418,10 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
     }
   }
 
+#ifdef PTX_WAVE_PROFILE
+  if (STATS && (threadIdx.x & 63u) == 0u)
+    for (int k = 0; k < 16; k++) atomicAdd(&gWaveProfile[k], prof[k]);
+#endif
   if (STATS) {
     atomicAdd(&stats->rays, (unsigned long long)nRays);
     atomicAdd(&stats->nodeSteps, (unsigned long long)nNodeSteps);
@@ -378,6 +430,93 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
     atomicAdd(&stats->hits, (unsigned long long)nHits);
     atomicAdd(&stats->misses, (unsigned long long)nMisses);
     atomicAdd(&stats->boxHits, nBoxHits);
+  }
+}
+
+// ---- cost-ordered schedule (no counterpart in the reference) ----
+// With one RNG stream per pixel (gpuRender.cu:130) a pixel's samples are sequential, so the pixel is
+// the unit of work and the frame ends when the last lane finishes its last pixel.  Pixel costs differ
+// by two orders of magnitude (sky: one ray per sample; a pixel inside the instance cloud: six long
+// rays), and each lane only gets a few pixels, so in raster order the chip idles through a long tail.
+// The pre-pass (kModeCost, one primary ray per pixel, about 0.3 % of a 100-spp frame) estimates the
+// cost of every 8x8 tile; tiles are then handed out most expensive first (longest-processing-time
+// order), which leaves only cheap pixels for the end of the frame.  The order of work does not change
+// any pixel's value.
+constexpr uint32_t kCostBuckets = 1024;
+
+__global__ void __launch_bounds__(256) tileCostKernel(const uint32_t* __restrict__ pixCost, uint32_t width, uint32_t height,
+                                                      uint32_t tilesX, uint32_t numTiles, uint32_t* __restrict__ tileCost,
+                                                      uint32_t* __restrict__ sched) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= numTiles) return;
+  const uint32_t ty = t / tilesX, tx = t - ty * tilesX;
+  uint32_t sum = 0;
+  for (uint32_t j = 0; j < 8u; j++) {
+    const uint32_t y = ty * 8u + j;
+    if (y >= height) break;
+    for (uint32_t i = 0; i < 8u; i++) {
+      const uint32_t x = tx * 8u + i;
+      if (x < width) sum += min(pixCost[y * width + x], 1u << 24);
+    }
+  }
+  tileCost[t] = sum;
+  atomicMax(&sched[0], sum);  // sched[0] = largest tile cost, sched[1..kCostBuckets] = histogram / offsets
+}
+
+__device__ __forceinline__ uint32_t costBucket(uint32_t cost, uint32_t maxCost) {  // bucket 0 = most expensive
+  const uint32_t q = maxCost ? (uint32_t)(((unsigned long long)cost * (kCostBuckets - 1u)) / maxCost) : 0u;
+  return (kCostBuckets - 1u) - min(q, kCostBuckets - 1u);
+}
+
+__global__ void __launch_bounds__(256) tileHistKernel(const uint32_t* __restrict__ tileCost, uint32_t numTiles, uint32_t* __restrict__ sched) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= numTiles) return;
+  atomicAdd(&sched[1u + costBucket(tileCost[t], sched[0])], 1u);
+}
+
+__global__ void __launch_bounds__(kCostBuckets) tileScanKernel(uint32_t* __restrict__ sched) {  // one block: counts -> start offsets
+  __shared__ uint32_t buf[kCostBuckets];
+  const uint32_t i = threadIdx.x;
+  const uint32_t mine = sched[1u + i];
+  buf[i] = mine;
+  __syncthreads();
+  for (uint32_t step = 1; step < kCostBuckets; step <<= 1) {
+    const uint32_t add = i >= step ? buf[i - step] : 0u;
+    __syncthreads();
+    buf[i] += add;
+    __syncthreads();
+  }
+  sched[1u + i] = buf[i] - mine;
+}
+
+__global__ void __launch_bounds__(256) tileScatterKernel(const uint32_t* __restrict__ tileCost, uint32_t numTiles, uint32_t* __restrict__ sched,
+                                                         uint32_t* __restrict__ tileOrder) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= numTiles) return;
+  // sched[0] is still the maximum: the scan left it alone
+  const uint32_t pos = atomicAdd(&sched[1u + costBucket(tileCost[t], sched[0])], 1u);
+  tileOrder[pos] = t;  // order inside a bucket is arbitrary (and irrelevant to the result)
+}
+
+// Adds the per-stream planes of a sub-stream launch in stream order; writes the accumulation buffer
+// (sum, samples) or, with `resolve`, the finished pixel.
+__global__ void __launch_bounds__(256) combineKernel(const float4* __restrict__ planes, uint32_t nStreams, uint32_t nPixels,
+                                                     void* __restrict__ out, bool resolve) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nPixels) return;
+  float4 a = planes[i];
+  for (uint32_t k = 1; k < nStreams; k++) {
+    const float4 b = planes[(size_t)k * nPixels + i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  if (resolve) {
+    const vec3 c = resolvePixel(vec3(a.x, a.y, a.z), a.w);
+    float* o = reinterpret_cast<float*>(out);
+    o[3ull * i + 0] = c.x;
+    o[3ull * i + 1] = c.y;
+    o[3ull * i + 2] = c.z;
+  } else {
+    reinterpret_cast<float4*>(out)[i] = a;
   }
 }
 

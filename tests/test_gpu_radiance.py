@@ -119,6 +119,45 @@ def test_sample_slice_streams(gpu_scenes):
     assert np.array_equal(s0, buf.cpu().numpy())
 
 
+def test_sub_streams_equal_the_sum_of_their_streams(gpu_scenes):
+    """ptx_params.sub_streams: S RNG streams per pixel inside one call == S single-stream calls with
+    stream ids part_index*S + k and the same split of the samples, added in stream order."""
+    torch = pytest.importorskip("torch")
+    hosts, devs = gpu_scenes
+    W, H, SPP, B, S, PART = 96, 64, 10, 4, 4, 1
+    buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    p = ptamd.make_params(W, H, spp=SPP, max_bounces=B, seed_mode=ptamd.SEED_STREAM, part_index=PART, part_count=2,
+                          sub_streams=S)
+    devs[2].accumulate_device(hosts[2].camera, p, buf.data_ptr(), None)
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy().copy()
+    assert np.all(got[..., 3] == SPP)
+    gpu_sum = np.zeros((H, W, 4), dtype=np.float32)
+    cpu_sum = np.zeros((H, W, 4), dtype=np.float32)
+    for k in range(S):
+        n = SPP // S + (1 if k < SPP % S else 0)
+        pk = ptamd.make_params(W, H, spp=n, max_bounces=B, seed_mode=ptamd.SEED_STREAM, part_index=PART * S + k,
+                               part_count=2 * S)
+        devs[2].accumulate_device(hosts[2].camera, pk, buf.data_ptr(), None)
+        torch.cuda.synchronize()
+        gpu_sum += buf.cpu().numpy()
+        a, _ = ob.accumulate(hosts[2], pk, seed_mode=ptamd.SEED_STREAM)
+        cpu_sum += a
+    assert np.array_equal(got, gpu_sum)  # same streams, same order of additions
+    assert rmse(ob.resolve(got), ob.resolve(cpu_sum)) < 2e-3
+    # the host-buffer entry point goes through the same planes + combine path
+    img, _ = devs[2].render(hosts[2].camera, p)
+    assert np.abs(img - ob.resolve(got)).max() < 1e-5
+    # more streams than samples: clamped, no empty streams
+    p1 = ptamd.make_params(W, H, spp=2, max_bounces=B, seed_mode=ptamd.SEED_STREAM, sub_streams=16)
+    devs[2].accumulate_device(hosts[2].camera, p1, buf.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert np.all(buf.cpu().numpy()[..., 3] == 2)
+    # the reference's seeding has one stream per pixel
+    with pytest.raises(Exception):
+        devs[2].render(hosts[2].camera, ptamd.make_params(W, H, spp=4, max_bounces=B, sub_streams=2))
+
+
 def test_single_rank_orchestration_on_gpu(gpu_scenes):
     pytest.importorskip("torch")
     import multigpu

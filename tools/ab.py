@@ -16,7 +16,8 @@ sys.path.insert(0, os.path.join(%(repo)r, "path-tracer_amd", "py")); sys.path.in
 import numpy as np, ptamd
 scene_id, spp, check = %(scene)d, %(spp)d, %(check)d
 s = ptamd.HostScene(scene_id); d = ptamd.DeviceScene(s.desc_ptr)
-p = ptamd.make_params(1500, 800, spp=spp, max_bounces=6)
+ss = int(os.environ.get("AB_STREAMS", "0"))
+p = ptamd.make_params(1500, 800, spp=spp, max_bounces=6, seed_mode=1 if ss > 1 else 0, sub_streams=ss)
 ts = []
 for i in range(%(iters)d):
     img, st = d.render(s.camera, p); ts.append(st.render_s)
@@ -43,8 +44,12 @@ def main():
     res = {n: [] for n in a.names}
     for r in range(a.rounds):
         for n in a.names:
-            lib = "libptx_backend.so" if n == "base" else f"libptx_backend_{n}.so"
+            parts = n.split(":")  # name[:ENV=VALUE...]
+            lib = "libptx_backend.so" if parts[0] == "base" else f"libptx_backend_{parts[0]}.so"
             env = dict(os.environ, PTX_BACKEND_LIB=os.path.join(REPO, "path-tracer_amd", "lib", lib))
+            for kv in parts[1:]:
+                k, v = kv.split("=", 1)
+                env[k] = v
             code = CHILD % {"repo": REPO, "scene": a.scene, "spp": a.spp, "check": a.check if r == 0 else 0, "iters": a.iters}
             out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
             if out.returncode != 0:
@@ -56,7 +61,7 @@ def main():
     print("\nsummary (min render ms over all rounds):")
     for n in a.names:
         if res[n]:
-            print(f"  {n:12s} {min(min(j['render_ms']) for j in res[n]):9.2f} ms   counts {min(j['counts_ms'] for j in res[n]):7.3f} ms  exact={res[n][0].get('counts_exact')}")
+            print(f"  {n:28s} {min(min(j['render_ms']) for j in res[n]):9.2f} ms   counts {min(j['counts_ms'] for j in res[n]):7.3f} ms  exact={res[n][0].get('counts_exact')}")
 
 
 if __name__ == "__main__":

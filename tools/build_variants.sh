@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/.."
 while [ $# -gt 1 ]; do
   name=$1; flags=$2; shift 2
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Iinclude \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Iinclude \
      -fhip-fp32-correctly-rounded-divide-sqrt $flags -shared -o path-tracer_amd/lib/libptx_backend_$name.so path-tracer_amd/csrc/ptx_backend.hip &
 done
 wait

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Wave-level execution profile of the path kernel's main loop (run on the GPU box).
+Needs a profiling build:  tools/build_variants.sh prof "-DPTX_WAVE_PROFILE"
+usage: tools/wave_profile.py [--scene 1] [--spp 4] [--lib prof]"""
+import argparse, ctypes, json, os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", type=int, default=1)
+ap.add_argument("--spp", type=int, default=4)
+ap.add_argument("--lib", default="prof")
+ap.add_argument("--streams", type=int, default=0)
+a = ap.parse_args()
+os.environ["PTX_BACKEND_LIB"] = os.path.join(REPO, "path-tracer_amd", "lib", f"libptx_backend_{a.lib}.so")
+sys.path.insert(0, os.path.join(REPO, "path-tracer_amd", "py"))
+import ptamd
+s = ptamd.HostScene(a.scene)
+d = ptamd.DeviceScene(s.desc_ptr)
+p = ptamd.make_params(1500, 800, spp=a.spp, max_bounces=6, seed_mode=1 if a.streams > 1 else 0, sub_streams=a.streams)
+lib = ctypes.CDLL(os.environ["PTX_BACKEND_LIB"])
+buf = (ctypes.c_ulonglong * 32)()
+lib.ptx_debug_wave_profile(buf)  # clear
+st = d.measure(s.camera, p)
+assert lib.ptx_debug_wave_profile(buf) == 0
+names = ["loop", "shade", "step", "exit", "enter", "tri", "node", "node-exact"]
+iters = buf[0]
+out = {"rays": st.rays, "node_steps": st.node_steps, "tri_tests": st.tri_tests, "inst_entries": st.inst_entries, "render_s": st.render_s}
+print(json.dumps(out))
+print(f"{'body':12s} {'iterations':>14s} {'frac of loop':>13s} {'lanes/iter':>11s} {'lane total':>14s}")
+for k, n in enumerate(names):
+    it, ln = buf[2 * k], buf[2 * k + 1]
+    print(f"{n:12s} {it:14d} {it / max(iters, 1):13.3f} {ln / max(it, 1):11.2f} {ln:14d}")
