@@ -5,9 +5,18 @@
 
 One process per GPU (the driver launches N>1 through torch.distributed.run; RCCL = backend "nccl").
 A step is one full pass of the hot path: every rank path-traces the whole 1500x800 frame at 100 spp
-with its own RNG stream (sample-slice partition, weak scaling: the job is an N*100-spp frame), the
+with its own RNG streams (sample-slice partition, weak scaling: the job is an N*100-spp frame), the
 un-normalised float accumulation buffers are summed onto rank 0 with one RCCL reduce, and rank 0
 divides, colour-grades and tonemaps.  The scene is resident in HBM before the timed region.
+
+RNG streams: the reference seeds one serial stream per pixel (gpuRender.cu:130), i.e. 1.2 M
+independent chains of 100 samples for this frame -- fewer than four per lane of an MI355X, so the
+chip idles through a long tail.  The same sample-slice construct that splits a frame over GPUs is
+therefore also used inside a GPU: --sub-streams S (default 10) gives every pixel S streams of
+100/S samples, each a work item of its own (ptx_params.sub_streams; parity against the sum of the
+oracle's streams in tests/test_gpu_radiance.py).  The frame with the reference's own seeding
+(S = 1, bit-compatible with gpuRender.cu's random sequence) is timed too and reported under
+config.reference_seeding.
 
 A ray is one call of Scene::intersect (gpuRender.cu:32): rays per step are counted exactly by an
 instrumented launch of the same kernel (paths are deterministic in pixel and seed), outside the
@@ -63,6 +72,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sub-streams", type=int, default=10, help="RNG streams per pixel and GPU (1 = the reference's seeding)")
     ap.add_argument("--spp", type=int, default=SPP, help=argparse.SUPPRESS)  # profiling runs only
     args = ap.parse_args()
 
@@ -88,9 +98,10 @@ def main():
     scene = ptamd.HostScene(SCENE)  # replicated on every GPU
     dscene = ptamd.DeviceScene(scene.desc_ptr, device=local_rank)
     params = ptamd.make_params(WIDTH, HEIGHT, spp=spp, max_bounces=BOUNCES, seed_mode=ptamd.SEED_STREAM,
-                               part_index=rank, part_count=world)
+                               part_index=rank, part_count=world, sub_streams=args.sub_streams)
     accum = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev)
     out = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=dev)
+    out1 = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=dev)
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
@@ -126,6 +137,21 @@ def main():
     total_rays = rays.item()
     elapsed = tmax.item()
 
+    ref_seed = None
+    if rank == 0 and world == 1 and args.sub_streams > 1:
+        # the same frame with the reference's seeding (one stream per pixel), one step, for the record
+        p1 = ptamd.make_params(WIDTH, HEIGHT, spp=spp, max_bounces=BOUNCES, seed_mode=ptamd.SEED_REFERENCE_GPU)
+        st1 = dscene.measure(scene.camera, p1)
+        stream = torch.cuda.current_stream().cuda_stream
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        dscene.accumulate_device(scene.camera, p1, accum.data_ptr(), stream)
+        dscene.resolve_device(accum.data_ptr(), WIDTH, HEIGHT, out1.data_ptr(), stream)
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        ref_seed = {"value": st1.rays / dt1 / 1e6, "unit": "Mrays/s", "ms_per_step": dt1 * 1e3, "rays_per_step": st1.rays,
+                    "steps": 1}
+
     if rank == 0:
         img = out.cpu().numpy()
         if not (img == img).all() or img.min() < 0.0 or img.max() > 1.0 or img.std() == 0.0:
@@ -154,8 +180,10 @@ def main():
                 "geometry": "procedural stand-in bust (models/bust-of-menelaus.stl absent)"
                             if scene.info.stand_in_geometry else "bust-of-menelaus.stl",
                 "environment": "analytic stand-in sky (HDR absent)" if scene.info.stand_in_environment else "HDR",
-                "partition": "whole frame per GPU, one RNG stream per GPU, RCCL sum-reduce of W*H*4 f32 to rank 0"
+                "partition": "whole frame per GPU, own RNG streams per GPU, RCCL sum-reduce of W*H*4 f32 to rank 0"
                              if world > 1 else "single GPU",
+                "rng_streams_per_pixel_per_gpu": args.sub_streams,
+                "reference_seeding": ref_seed,
                 "rays_per_step": total_rays, "paths_per_step": WIDTH * HEIGHT * spp * world,
             },
             "roofline": {

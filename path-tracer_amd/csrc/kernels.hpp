@@ -46,7 +46,7 @@ constexpr uint32_t kBlockThreads = 256;  // 4 waves
 constexpr uint32_t kLdsStack = PTX_LDS_STACK;  // stack entries per lane kept in LDS (1 KB per entry per block)
 // Tunables (see DESIGN.md "Scheduling inside a wave").
 #ifndef PTX_SHADE_THRESHOLD
-#define PTX_SHADE_THRESHOLD 12  // waiting lanes that trigger the shading phase
+#define PTX_SHADE_THRESHOLD 16  // waiting lanes that trigger the shading phase
 #endif
 #ifndef PTX_ENTER_THRESHOLD
 #define PTX_ENTER_THRESHOLD 1   // lanes at a TLAS leaf before the (rare, long) instance-entry body is run
@@ -70,14 +70,28 @@ constexpr uint32_t kLdsStack = PTX_LDS_STACK;  // stack entries per lane kept in
 // [2k+1] = lanes that were active in it.
 #ifdef PTX_WAVE_PROFILE
 __device__ unsigned long long gWaveProfile[32];
+#endif
+#if defined(PTX_WAVE_PROFILE) && !defined(PTX_TIME_PROFILE)
 #define PTX_PROF(k, lanes) do { if (STATS) { prof[2 * (k)] += 1u; prof[2 * (k) + 1] += (uint32_t)__popcll(__ballot(lanes)); } } while (0)
 #else
 #define PTX_PROF(k, lanes) do {} while (0)
 #endif
+// Wall-clock profile of the loop's regions (profiling builds only: -DPTX_TIME_PROFILE, with
+// -DPTX_WAVE_PROFILE): shader-clock ticks per region summed over all waves into gWaveProfile[16 + k].
+#if defined(PTX_WAVE_PROFILE) && defined(PTX_TIME_PROFILE)
+#define PTX_STAMP(k) do { if (STATS) { const unsigned long long now_ = __builtin_readcyclecounter(); tprof[k] += now_ - tlast; tlast = now_; } } while (0)
+#define PTX_WAIT_ALL() do { if (STATS) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); } while (0)
+#else
+#define PTX_STAMP(k) do {} while (0)
+#define PTX_WAIT_ALL() do {} while (0)
+#endif
+
+#ifdef PTX_VISIT_HIST
+__device__ unsigned int gVisitHist[1u << 20];  // node steps per pair index (profiling builds only)
+#endif
 
 constexpr int kModeCounts = 0;    // `-a`: gpuRender.cu:146-150
 constexpr int kModeRadiance = 1;  // gpuRender.cu:132-169
-constexpr int kModeCost = 2;      // scheduling pre-pass: primary ray only, writes a per-pixel cost estimate
 
 // Per-lane traversal stack: entries [0, kLdsStack) live in LDS as sStack[entry][thread] (consecutive
 // lanes -> consecutive banks); deeper entries go to a per-launch global overflow buffer laid out
@@ -116,17 +130,7 @@ __device__ __forceinline__ void stackWrite(const StackMem& m, uint32_t slot, uin
 // Work item -> pixel.  The image is cut into bands of 8 rows; inside a band items run down a column
 // first, so 64 consecutive items (one wave's first fetch) form an 8x8 block of adjacent pixels for
 // any image size, with no padding items.
-__device__ __forceinline__ bool workPixel(const FrameConstants& fc, const uint32_t* __restrict__ tileOrder, uint32_t w, uint32_t& x,
-                                          uint32_t& y) {
-  if (tileOrder) {
-    // cost-ordered schedule: 64 consecutive items = one 8x8 tile, tiles in the order of the pre-pass
-    // (most expensive first); items of an edge tile that fall outside the image are skipped
-    const uint32_t t = tileOrder[w >> 6], i = w & 63u;
-    const uint32_t ty = t / fc.tilesX, tx = t - ty * fc.tilesX;
-    x = tx * 8u + (i >> 3);
-    y = ty * 8u + (i & 7u);
-    return x < fc.width && y < fc.height;
-  }
+__device__ __forceinline__ void workPixel(const FrameConstants& fc, uint32_t w, uint32_t& x, uint32_t& y) {
   const uint32_t bandItems = fc.width * 8u;
   const uint32_t band = w / bandItems;
   const uint32_t r = w - band * bandItems;
@@ -134,14 +138,13 @@ __device__ __forceinline__ bool workPixel(const FrameConstants& fc, const uint32
   const uint32_t cx = r / rows;
   x = cx;
   y = band * 8u + (r - cx * rows);
-  return true;
 }
 
 template <int MODE, bool STATS, bool RESOLVE>
 __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(DeviceScene sc, FrameConstants fc, uint32_t* workCounter,
                                                             void* __restrict__ outRaw, DeviceStats* stats,
-                                                            uint32_t* stackOverflow, const uint32_t* __restrict__ tileOrder) {
-  constexpr bool kOneRay = MODE != kModeRadiance;  // heat map / cost pre-pass: one primary ray per pixel
+                                                            uint32_t* stackOverflow) {
+  constexpr bool kOneRay = MODE == kModeCounts;  // heat map: one primary ray per pixel
   __shared__ uint32_t sStack[kLdsStack * kBlockThreads];
   StackMem stk;
   stk.lds = sStack + threadIdx.x;
@@ -150,8 +153,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
   uint32_t sp = 1;
 
   const uint32_t nPixels = fc.width * fc.height;
-  const uint32_t itemsPerStream = tileOrder ? fc.tilesX * fc.tilesY * 64u : nPixels;
-  const uint32_t totalWork = itemsPerStream * fc.subStreams;  // checked on the host to fit 32 bits
+  const uint32_t totalWork = nPixels * fc.subStreams;  // checked on the host to fit 32 bits
   const vec3 camPos(fc.camPos[0], fc.camPos[1], fc.camPos[2]);
 
   // ---- lane state ----
@@ -159,6 +161,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
   bool pending = false;      // a traced ray's result waits for the shading phase
   bool havePixel = false;
   bool zeroDir = false;      // a component of the current ray's direction is exactly 0 (0*inf possible)
+  bool wZeroDir = false;     // the same for the world-space ray (restored when an instance is left)
   uint32_t pix = 0;     // pixel index (bits 0..23) | RNG stream of this item (bits 24..31)
   uint32_t sample = 0;  // samples (rays, for the one-ray modes) this item still has to do; 0 = pull the next item
   uint32_t bounce = 0, rng = 0, count = 0;
@@ -175,6 +178,10 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
 
 #ifdef PTX_WAVE_PROFILE
   unsigned long long prof[16] = {};
+#ifdef PTX_TIME_PROFILE
+  unsigned long long tprof[8] = {};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#endif
 #endif
   uint32_t loopCount = 0;
   for (;;) {
@@ -198,10 +205,6 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
           if (kOneRay) sample = 0u;
           if (MODE == kModeCounts) {
             reinterpret_cast<uint32_t*>(outRaw)[pix] = count;
-          } else if (MODE == kModeCost) {
-            // a pixel whose primary ray hits geometry goes on bouncing inside the scene; one that
-            // leaves it ends after one ray per sample
-            reinterpret_cast<uint32_t*>(outRaw)[pix] = (hit.t < FLT_MAX) ? 8u * count + 64u : count + 1u;
           } else if (hit.t < FLT_MAX) {
             if (STATS) nHits++;
             shadeHit(sc, hit, wo, wd, rng, col);  // writes the next ray into wo / wd
@@ -239,12 +242,9 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
               havePixel = false;
               break;
             }
-            const uint32_t k = fc.subStreams > 1u ? w / itemsPerStream : 0u;
+            const uint32_t k = fc.subStreams > 1u ? w / nPixels : 0u;
             uint32_t x, y;
-            if (!workPixel(fc, tileOrder, w - k * itemsPerStream, x, y)) {
-              havePixel = false;
-              continue;  // outside the image (edge tile): pull the next item
-            }
+            workPixel(fc, w - k * nPixels, x, y);
             const uint32_t p = y * fc.width + x;
             pix = p | (k << 24);
             sum = vec3(0.0f);
@@ -282,9 +282,9 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
         }
         if (live) {
           // ---- launch the segment: Scene::intersect starts at the TLAS root ----
-          winv = 1.0f / wd;
+          reciprocalDir(wd, winv, wZeroDir);
+          zeroDir = wZeroDir;
           o = wo; d = wd; inv = winv;
-          zeroDir = (wd.x == 0.0f) || (wd.y == 0.0f) || (wd.z == 0.0f);
           hit.t = FLT_MAX; hit.u = 0.0f; hit.v = 0.0f; hit.tri = 0xFFFFFFFFu; hit.inst = 0xFFFFFFFFu;
           count = 0u;
           tlasLeaf = 0u;
@@ -298,6 +298,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       }
     }
 
+    PTX_STAMP(0);  // shading phase (and the loop-top checks)
     // ============================== traversal steps, one per lane each ===============================
 #pragma unroll 1
     for (int it = 0; it < PTX_INNER_ITERS; it++) {
@@ -328,15 +329,26 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       const bool deep = __any(sp + 2u >= kLdsStack);  // wave-uniform; false almost always
       const uint32_t top = stackRead(stk, sp ? sp - 1u : 0u, deep);
 
-      // record address in 16-byte units from the arena base; lanes with nothing to fetch read the
-      // first record of the arena (same line for all of them) so that the loads need no predication
-      const uint32_t off16 = isNode ? sc.pairs16 + ref * 4u : (isTri ? sc.tris16 + first * 3u : (isEnter ? sc.inst16 + first * 4u : 0u));
+      // Record fetch.  The loop is bound by the vector memory path, whose cost is per load instruction
+      // and active lane (tools/ubench_gather2.hip: ~45 cycles per divergent 64-lane load whatever its
+      // width), so every lane fetches only what its step uses: nothing for lanes that wait or leave an
+      // instance, three quarters for a triangle.  (Keeping the most visited NodePairs in LDS was tried
+      // and lost: the hottest pairs are the ones many lanes of a wave read together, which the memory
+      // path already serves as one access.)
+      const bool fetch3 = isNode || isTri || isEnter;
+      const bool fetch4 = isNode || isEnter;
+      const uint32_t off16 = isNode ? sc.pairs16 + ref * 4u : (isTri ? sc.tris16 + first * 3u : sc.inst16 + first * 4u);
       const float4* rp = sc.arena + off16;
-      const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+      float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0, r3 = r0;
+      if (fetch3) { r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; }
+      if (fetch4) r3 = rp[3];
 
       uint32_t newRef = ref;
       uint32_t pushVal = 0u;
       bool doPush = false, doPop = false;
+      PTX_STAMP(1);  // decode, addresses, loads issued
+      PTX_WAIT_ALL();
+      PTX_STAMP(2);  // waiting for the record and the stack top
 
       PTX_PROF(2, steps);
       if (__any(isExit)) PTX_PROF(3, isExit);
@@ -350,11 +362,12 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
         // lowered t (intersection.hpp:184-189).
         if (hit.t < tBeforeInst) hit.inst = curInst;
         o = wo; d = wd; inv = winv;
-        zeroDir = (wd.x == 0.0f) || (wd.y == 0.0f) || (wd.z == 0.0f);
+        zeroDir = wZeroDir;
         doPop = tlasLeaf == 0u;
         newRef = doPop ? top : tlasLeaf;
         tlasLeaf = 0u;
       }
+      PTX_STAMP(3);
       PTX_MARK("ENTER");
       if (isEnter) {
         // TLAS leaf: enter its first instance, keep the rest of the leaf (gpuFunctions.hpp:32-41).
@@ -362,14 +375,14 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
         curInst = first;
         o = xformRows(r0, r1, r2, wo, 1.0f);
         d = xformRows(r0, r1, r2, wd, 0.0f);  // not normalised: t stays world-space
-        inv = 1.0f / d;
-        zeroDir = (d.x == 0.0f) || (d.y == 0.0f) || (d.z == 0.0f);
+        reciprocalDir(d, inv, zeroDir);
         tBeforeInst = hit.t;
         if (STATS) nInstEntries++;
         pushVal = kRefInstExit;
         doPush = true;
         newRef = __float_as_uint(r3.x);  // InstXform::rootRef
       }
+      PTX_STAMP(4);
       PTX_MARK("TRI");
       if (isTri) {
         // BLAS leaf, one triangle per step, in order, strict `<` (intersection.hpp:9-44, :112-122).
@@ -384,36 +397,49 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
         doPop = nPrim == 1u;
         newRef = doPop ? top : makeLeafRef(first + 1u, nPrim - 1u);
       }
+      PTX_STAMP(5);
       PTX_MARK("NODE");
       if (isNode) {
         // Internal node (intersection.hpp:133-161 / :201-230): one 64-byte record holds both children.
-        float d1, d2;
+        float t1, t2;
+        bool h1, h2;
         if (__any(zeroDir)) {
-          d1 = slabTest<true>(o, inv, hit.t, r0, r1);
-          d2 = slabTest<true>(o, inv, hit.t, r2, r3);
+          h1 = slabHit<true>(o, inv, hit.t, r0, r1, t1);
+          h2 = slabHit<true>(o, inv, hit.t, r2, r3, t2);
         } else {
-          d1 = slabTest<false>(o, inv, hit.t, r0, r1);
-          d2 = slabTest<false>(o, inv, hit.t, r2, r3);
+          h1 = slabHit<false>(o, inv, hit.t, r0, r1, t1);
+          h2 = slabHit<false>(o, inv, hit.t, r2, r3, t2);
         }
         const uint32_t rl = __float_as_uint(r0.w), rr = __float_as_uint(r2.w);
         if (STATS) nNodeSteps++;
-        const bool swap = d1 > d2;  // nearer child first; ties keep the left child
-        const float dn = swap ? d2 : d1, df = swap ? d1 : d2;
+#ifdef PTX_VISIT_HIST
+        if (STATS && ref < (1u << 20)) atomicAdd(&gVisitHist[ref], 1u);
+#endif
+        // The reference compares d = hit ? tmin : FLT_MAX of the two children and visits the nearer one
+        // first, ties keeping the left child (intersection.hpp:139-152); a hit's tmin is < ray.t <=
+        // FLT_MAX, so "d1 > d2" is exactly: right hit, and left missed or farther.
+#ifdef PTX_VALUE_ORDER
+        const bool swap = (h1 ? t1 : FLT_MAX) > (h2 ? t2 : FLT_MAX);
+#else
+        const bool swap = h2 && (!h1 || t1 > t2);
+#endif
         const uint32_t rn = swap ? rr : rl, rf = swap ? rl : rr;
-        const bool hitNear = dn != FLT_MAX, hitFar = df != FLT_MAX;  // far hit implies near hit
-        count += (hitNear ? 1u : 0u) + (hitFar ? 1u : 0u);  // counted when pushed, not re-tested when popped
+        const bool hitNear = h1 || h2, hitFar = h1 && h2;
+        count += (h1 ? 1u : 0u) + (h2 ? 1u : 0u);  // counted when pushed, not re-tested when popped
         pushVal = rf;
         doPush = hitFar;
         doPop = !hitNear;
         newRef = hitNear ? rn : top;
       }
 
+      PTX_STAMP(6);
       PTX_MARK("MERGE");
       if (steps) {
         stackWrite(stk, sp, pushVal, deep);
         sp = sp + (doPush ? 1u : 0u) - (doPop ? 1u : 0u);
         ref = newRef;
       }
+      PTX_STAMP(7);
       PTX_MARK("TRAV_END");
     }
   }
@@ -421,6 +447,11 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
 #ifdef PTX_WAVE_PROFILE
   if (STATS && (threadIdx.x & 63u) == 0u)
     for (int k = 0; k < 16; k++) atomicAdd(&gWaveProfile[k], prof[k]);
+#ifdef PTX_TIME_PROFILE
+  if (STATS && (threadIdx.x & 63u) == 0u)
+    for (int k = 0; k < 8; k++) atomicAdd(&gWaveProfile[16 + k], tprof[k]);
+  if (STATS && (threadIdx.x & 63u) == 0u) atomicAdd(&gWaveProfile[0], (unsigned long long)loopCount);
+#endif
 #endif
   if (STATS) {
     atomicAdd(&stats->rays, (unsigned long long)nRays);
@@ -431,71 +462,6 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
     atomicAdd(&stats->misses, (unsigned long long)nMisses);
     atomicAdd(&stats->boxHits, nBoxHits);
   }
-}
-
-// ---- cost-ordered schedule (no counterpart in the reference) ----
-// With one RNG stream per pixel (gpuRender.cu:130) a pixel's samples are sequential, so the pixel is
-// the unit of work and the frame ends when the last lane finishes its last pixel.  Pixel costs differ
-// by two orders of magnitude (sky: one ray per sample; a pixel inside the instance cloud: six long
-// rays), and each lane only gets a few pixels, so in raster order the chip idles through a long tail.
-// The pre-pass (kModeCost, one primary ray per pixel, about 0.3 % of a 100-spp frame) estimates the
-// cost of every 8x8 tile; tiles are then handed out most expensive first (longest-processing-time
-// order), which leaves only cheap pixels for the end of the frame.  The order of work does not change
-// any pixel's value.
-constexpr uint32_t kCostBuckets = 1024;
-
-__global__ void __launch_bounds__(256) tileCostKernel(const uint32_t* __restrict__ pixCost, uint32_t width, uint32_t height,
-                                                      uint32_t tilesX, uint32_t numTiles, uint32_t* __restrict__ tileCost,
-                                                      uint32_t* __restrict__ sched) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= numTiles) return;
-  const uint32_t ty = t / tilesX, tx = t - ty * tilesX;
-  uint32_t sum = 0;
-  for (uint32_t j = 0; j < 8u; j++) {
-    const uint32_t y = ty * 8u + j;
-    if (y >= height) break;
-    for (uint32_t i = 0; i < 8u; i++) {
-      const uint32_t x = tx * 8u + i;
-      if (x < width) sum += min(pixCost[y * width + x], 1u << 24);
-    }
-  }
-  tileCost[t] = sum;
-  atomicMax(&sched[0], sum);  // sched[0] = largest tile cost, sched[1..kCostBuckets] = histogram / offsets
-}
-
-__device__ __forceinline__ uint32_t costBucket(uint32_t cost, uint32_t maxCost) {  // bucket 0 = most expensive
-  const uint32_t q = maxCost ? (uint32_t)(((unsigned long long)cost * (kCostBuckets - 1u)) / maxCost) : 0u;
-  return (kCostBuckets - 1u) - min(q, kCostBuckets - 1u);
-}
-
-__global__ void __launch_bounds__(256) tileHistKernel(const uint32_t* __restrict__ tileCost, uint32_t numTiles, uint32_t* __restrict__ sched) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= numTiles) return;
-  atomicAdd(&sched[1u + costBucket(tileCost[t], sched[0])], 1u);
-}
-
-__global__ void __launch_bounds__(kCostBuckets) tileScanKernel(uint32_t* __restrict__ sched) {  // one block: counts -> start offsets
-  __shared__ uint32_t buf[kCostBuckets];
-  const uint32_t i = threadIdx.x;
-  const uint32_t mine = sched[1u + i];
-  buf[i] = mine;
-  __syncthreads();
-  for (uint32_t step = 1; step < kCostBuckets; step <<= 1) {
-    const uint32_t add = i >= step ? buf[i - step] : 0u;
-    __syncthreads();
-    buf[i] += add;
-    __syncthreads();
-  }
-  sched[1u + i] = buf[i] - mine;
-}
-
-__global__ void __launch_bounds__(256) tileScatterKernel(const uint32_t* __restrict__ tileCost, uint32_t numTiles, uint32_t* __restrict__ sched,
-                                                         uint32_t* __restrict__ tileOrder) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= numTiles) return;
-  // sched[0] is still the maximum: the scan left it alone
-  const uint32_t pos = atomicAdd(&sched[1u + costBucket(tileCost[t], sched[0])], 1u);
-  tileOrder[pos] = t;  // order inside a bucket is arbitrary (and irrelevant to the result)
 }
 
 // Adds the per-stream planes of a sub-stream launch in stream order; writes the accumulation buffer

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -130,16 +131,8 @@ struct ptx_scene {
   size_t ovfBytes = 0;
   int numCus = 0;
   hipEvent_t evStart = nullptr, evStop = nullptr;
-  hipEvent_t evPre = nullptr;  // recorded in front of the scheduling pre-pass
   hipStream_t lastStream = nullptr;
   bool timed = false;
-  bool prePass = false;  // the last radiance launch ran the scheduling pre-pass
-  // cost-ordered schedule (kernels.hpp): per-pixel cost, per-tile cost, histogram / offsets, tile order
-  uint32_t* dPixCost = nullptr;
-  uint32_t* dTileCost = nullptr;
-  uint32_t* dSched = nullptr;
-  uint32_t* dTileOrder = nullptr;
-  size_t schedPixels = 0, schedTiles = 0;
   float4* dPlanes = nullptr;  // per-stream accumulation planes of a sub-stream launch
   size_t planeBytes = 0;
 };
@@ -206,7 +199,7 @@ int makeFrame(const ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, 
   fc.partCount = prm->part_count;
   fc.tilesX = (prm->width + 7u) / 8u;
   fc.tilesY = (prm->height + 7u) / 8u;
-  if ((uint64_t)fc.tilesX * fc.tilesY * 64u * streams >= (1ull << 32)) return fail(PTX_ELIMIT, "pixels x sub_streams exceeds 2^32 work items");
+  if ((uint64_t)prm->width * prm->height * streams >= (1ull << 32)) return fail(PTX_ELIMIT, "pixels x sub_streams exceeds 2^32 work items");
   return PTX_OK;
 }
 
@@ -221,8 +214,7 @@ int persistentGrid(ptx_scene* s, K kernel, uint32_t& blocks) {
 }
 
 template <typename K>
-int launchPath(ptx_scene* s, K kernel, const FrameConstants& fc, void* dOut, hipStream_t stream,
-               const uint32_t* tileOrder = nullptr) {
+int launchPath(ptx_scene* s, K kernel, const FrameConstants& fc, void* dOut, hipStream_t stream) {
   uint32_t blocks = 0;
   int rc = persistentGrid(s, kernel, blocks);
   if (rc) return rc;
@@ -242,7 +234,7 @@ int launchPath(ptx_scene* s, K kernel, const FrameConstants& fc, void* dOut, hip
   }
   HIP_TRY(hipMemsetAsync(s->dWorkCounter, 0, sizeof(uint32_t), stream));
   HIP_TRY(hipEventRecord(s->evStart, stream));
-  kernel<<<dim3(blocks), dim3(kBlockThreads), 0, stream>>>(s->dev, fc, s->dWorkCounter, dOut, s->dStats, s->dOverflow, tileOrder);
+  kernel<<<dim3(blocks), dim3(kBlockThreads), 0, stream>>>(s->dev, fc, s->dWorkCounter, dOut, s->dStats, s->dOverflow);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->evStop, stream));
   s->lastStream = stream;
@@ -255,64 +247,7 @@ int launchCounts(ptx_scene* s, const FrameConstants& fc, uint32_t* dOut, hipStre
   return launchPath(s, pathKernel<kModeCounts, false, false>, fc, dOut, stream);
 }
 
-// Cost-ordered schedule (kernels.hpp): worth its pre-pass when a pixel is many rays long and the image
-// has many more tiles than a wave has lanes.  PTX_SCHEDULE=0 / 1 in the environment forces it off / on.
-bool wantSchedule(const FrameConstants& fc) {
-  static const char* env = getenv("PTX_SCHEDULE");
-  if (env && env[0] == '0') return false;
-  if (env && env[0] == '1') return true;
-  return (uint64_t)fc.spp * fc.maxBounces >= 8u && fc.tilesX * fc.tilesY >= 1024u;
-}
-
-int buildSchedule(ptx_scene* s, const FrameConstants& fc, hipStream_t stream) {
-  const size_t pixels = (size_t)fc.width * fc.height, tiles = (size_t)fc.tilesX * fc.tilesY;
-  if (s->schedPixels < pixels) {
-    if (s->dPixCost) HIP_TRY(hipFree(s->dPixCost));
-    s->dPixCost = nullptr;
-    s->schedPixels = 0;
-    HIP_TRY(hipMalloc((void**)&s->dPixCost, pixels * sizeof(uint32_t)));
-    s->schedPixels = pixels;
-  }
-  if (s->schedTiles < tiles) {
-    if (s->dTileCost) HIP_TRY(hipFree(s->dTileCost));
-    if (s->dTileOrder) HIP_TRY(hipFree(s->dTileOrder));
-    s->dTileCost = s->dTileOrder = nullptr;
-    s->schedTiles = 0;
-    HIP_TRY(hipMalloc((void**)&s->dTileCost, tiles * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&s->dTileOrder, tiles * sizeof(uint32_t)));
-    s->schedTiles = tiles;
-  }
-  if (!s->dSched) HIP_TRY(hipMalloc((void**)&s->dSched, (1u + kCostBuckets) * sizeof(uint32_t)));
-  FrameConstants pre = fc;  // primary rays only, whole frame, raster order
-  pre.spp = 1u;
-  pre.maxBounces = 1u;
-  pre.partIndex = 0u;
-  pre.partCount = 1u;
-  pre.subStreams = 1u;
-  pre.sppBase = 1u;
-  pre.sppExtra = 0u;
-  int rc = launchPath(s, pathKernel<kModeCost, false, false>, pre, s->dPixCost, stream);
-  if (rc) return rc;
-  HIP_TRY(hipMemsetAsync(s->dSched, 0, (1u + kCostBuckets) * sizeof(uint32_t), stream));
-  const uint32_t n = (uint32_t)tiles, grid = (n + 255u) / 256u;
-  tileCostKernel<<<dim3(grid), dim3(256), 0, stream>>>(s->dPixCost, fc.width, fc.height, fc.tilesX, n, s->dTileCost, s->dSched);
-  tileHistKernel<<<dim3(grid), dim3(256), 0, stream>>>(s->dTileCost, n, s->dSched);
-  tileScanKernel<<<dim3(1), dim3(kCostBuckets), 0, stream>>>(s->dSched);
-  tileScatterKernel<<<dim3(grid), dim3(256), 0, stream>>>(s->dTileCost, n, s->dSched, s->dTileOrder);
-  HIP_TRY(hipGetLastError());
-  return PTX_OK;
-}
-
 int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool resolve, hipStream_t stream, bool stats) {
-  const uint32_t* order = nullptr;
-  s->prePass = false;
-  if (wantSchedule(fc)) {
-    HIP_TRY(hipEventRecord(s->evPre, stream));
-    int rc = buildSchedule(s, fc, stream);
-    if (rc) return rc;
-    order = s->dTileOrder;
-    s->prePass = true;
-  }
   if (fc.subStreams > 1u) {
     // every stream of a pixel is a work item of its own and writes its own plane; the planes are
     // added in stream order afterwards (deterministic, unlike float atomics)
@@ -325,19 +260,19 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
       HIP_TRY(hipMalloc((void**)&s->dPlanes, bytes));
       s->planeBytes = bytes;
     }
-    int rc = stats ? launchPath(s, pathKernel<kModeRadiance, true, false>, fc, s->dPlanes, stream, order)
-                   : launchPath(s, pathKernel<kModeRadiance, false, false>, fc, s->dPlanes, stream, order);
+    int rc = stats ? launchPath(s, pathKernel<kModeRadiance, true, false>, fc, s->dPlanes, stream)
+                   : launchPath(s, pathKernel<kModeRadiance, false, false>, fc, s->dPlanes, stream);
     if (rc) return rc;
     combineKernel<<<dim3((nPixels + 255u) / 256u), dim3(256), 0, stream>>>(s->dPlanes, fc.subStreams, nPixels, dOut, resolve);
     HIP_TRY(hipGetLastError());
     return PTX_OK;
   }
   if (stats) {
-    if (resolve) return launchPath(s, pathKernel<kModeRadiance, true, true>, fc, dOut, stream, order);
-    return launchPath(s, pathKernel<kModeRadiance, true, false>, fc, dOut, stream, order);
+    if (resolve) return launchPath(s, pathKernel<kModeRadiance, true, true>, fc, dOut, stream);
+    return launchPath(s, pathKernel<kModeRadiance, true, false>, fc, dOut, stream);
   }
-  if (resolve) return launchPath(s, pathKernel<kModeRadiance, false, true>, fc, dOut, stream, order);
-  return launchPath(s, pathKernel<kModeRadiance, false, false>, fc, dOut, stream, order);
+  if (resolve) return launchPath(s, pathKernel<kModeRadiance, false, true>, fc, dOut, stream);
+  return launchPath(s, pathKernel<kModeRadiance, false, false>, fc, dOut, stream);
 }
 
 int kernelSeconds(ptx_scene* s, double* out) {
@@ -345,17 +280,6 @@ int kernelSeconds(ptx_scene* s, double* out) {
   HIP_TRY(hipEventSynchronize(s->evStop));
   float ms = 0.0f;
   HIP_TRY(hipEventElapsedTime(&ms, s->evStart, s->evStop));
-  *out = (double)ms * 1e-3;
-  return PTX_OK;
-}
-
-// Render time as the reference reports it (gpuRender.cu:274-283: everything between its two events),
-// i.e. including the scheduling pre-pass when one ran; kernelSeconds is the path kernel alone.
-int renderSeconds(ptx_scene* s, double* out) {
-  int rc = kernelSeconds(s, out);
-  if (rc || !s->prePass) return rc;
-  float ms = 0.0f;
-  HIP_TRY(hipEventElapsedTime(&ms, s->evPre, s->evStop));
   *out = (double)ms * 1e-3;
   return PTX_OK;
 }
@@ -434,6 +358,10 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
              blasDepth, kStackEntries);
     return fail(PTX_ELIMIT, buf);
   }
+
+  for (uint32_t i = 0; i < d->instance_count; i++)
+    if (d->instances[i].geometry_id >= d->geometry_count || d->instances[i].material_id >= d->material_count)
+      return fail(PTX_EINVAL, "instance refers to a missing geometry/material");
 
   std::vector<TriRec> tris(d->triangle_total);
   for (uint32_t i = 0; i < d->triangle_total; i++) {
@@ -532,7 +460,7 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
       up(oVn, vtxN.data(), vtxN.size() * sizeof(float4)),        up(oUv, d->vtx_uvs, (size_t)d->vtx_uv_total * sizeof(float2)),
       up(oMat, mats.data(), mats.size() * sizeof(MaterialRec)),  up(oTex, texs.data(), texs.size() * sizeof(TextureRec)),
       up(oTexels, texels.data(), texels.size() * sizeof(float4)), up(oEnv, env.data(), env.size() * sizeof(float4)),
-      hipMalloc((void**)&s->dStats, sizeof(DeviceStats)),        hipEventCreate(&s->evStart), hipEventCreate(&s->evStop), hipEventCreate(&s->evPre),
+      hipMalloc((void**)&s->dStats, sizeof(DeviceStats)),        hipEventCreate(&s->evStart), hipEventCreate(&s->evStop),
       hipMalloc((void**)&s->dWorkCounter, 256),                  hipDeviceGetAttribute(&s->numCus, hipDeviceAttributeMultiprocessorCount, device)};
   for (hipError_t er : errs)
     if (er != hipSuccess) {
@@ -576,11 +504,6 @@ void ptx_destroy(ptx_scene* s) {
   if (s->dWorkCounter) (void)hipFree(s->dWorkCounter);
   if (s->dOverflow) (void)hipFree(s->dOverflow);
   if (s->dPlanes) (void)hipFree(s->dPlanes);
-  if (s->dPixCost) (void)hipFree(s->dPixCost);
-  if (s->dTileCost) (void)hipFree(s->dTileCost);
-  if (s->dTileOrder) (void)hipFree(s->dTileOrder);
-  if (s->dSched) (void)hipFree(s->dSched);
-  if (s->evPre) (void)hipEventDestroy(s->evPre);
   if (s->evStart) (void)hipEventDestroy(s->evStart);
   if (s->evStop) (void)hipEventDestroy(s->evStop);
   delete s;
@@ -645,7 +568,7 @@ int ptx_render(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, float
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     stats->upload_s = s->uploadSeconds;
-    if ((rc = renderSeconds(s, &stats->render_s))) return rc;
+    if ((rc = kernelSeconds(s, &stats->render_s))) return rc;
   }
   return PTX_OK;
 }
@@ -683,6 +606,16 @@ extern "C" int ptx_debug_wave_profile(unsigned long long* out32) {
   if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(ptx::gWaveProfile), sizeof(unsigned long long) * 32) != hipSuccess) return -2;
   unsigned long long zero[32] = {};
   if (hipMemcpyToSymbol(HIP_SYMBOL(ptx::gWaveProfile), zero, sizeof(zero)) != hipSuccess) return -2;
+  return 0;
+}
+#endif
+
+#ifdef PTX_VISIT_HIST
+// Profiling builds only: node steps per pair index of the instrumented launches so far; also reports
+// where the TLAS pairs start and how many pairs there are (pairs are stored TLAS first).
+extern "C" int ptx_debug_visit_hist(unsigned int* out, unsigned int n) {
+  if (n > (1u << 20)) n = 1u << 20;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ptx::gVisitHist), sizeof(unsigned int) * n) != hipSuccess) return -2;
   return 0;
 }
 #endif

@@ -28,6 +28,59 @@ __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm
 // GLM's forms for every non-NaN input (a zero may differ in sign, which no comparison below can see).
 // A NaN can only appear in t1/t2 as 0 * inf, i.e. when a component of the ray direction is exactly
 // zero, so callers pick EXACT_NAN = true for a wave in which any lane holds such a ray.
+// 1.0f / x in three instructions instead of the ten of the IEEE division sequence: v_rcp_f32 and one
+// Newton step.  Checked against the correctly rounded quotient for every float (tools/rcp_check.hip,
+// ptx_selftest_reciprocal): bit-identical whenever the biased exponent of x is in [1, 252], i.e.
+// 2^-126 <= |x| < 2^126 (and NaN -> NaN); zeros, denormals, infinities and the two largest binades
+// differ, so callers guard the range and fall back to the division.
+__device__ __forceinline__ float rcpNewton(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  const float e = __builtin_fmaf(-x, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+}
+constexpr float kRcpLo = 0x1p-126f, kRcpHi = 0x1p126f;
+#ifndef PTX_FAST_RCP
+#define PTX_FAST_RCP 1
+#endif
+#ifndef PTX_FAST_RCP_TRI
+#define PTX_FAST_RCP_TRI 1
+#endif
+
+__device__ __forceinline__ float absMin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float absMax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// inv = 1.0f / d per component (intersection.hpp: ray.invDirection) and the "a component is exactly
+// zero" flag of the slab test.  Wave-uniform choice: all active lanes inside the checked range -> the
+// short sequence (and no component can be zero); otherwise the IEEE division for everyone.
+__device__ __forceinline__ void reciprocalDir(const vec3& d, vec3& inv, bool& zeroDir) {
+  const float lo = absMin3(d.x, d.y, d.z), hi = absMax3(d.x, d.y, d.z);  // NaNs are skipped: NaN -> NaN either way
+  const bool inRange = lo >= kRcpLo && hi < kRcpHi;
+  if (PTX_FAST_RCP && __all(inRange)) {
+    inv = vec3(rcpNewton(d.x), rcpNewton(d.y), rcpNewton(d.z));
+    zeroDir = false;
+  } else {
+    inv = 1.0f / d;
+    zeroDir = (d.x == 0.0f) || (d.y == 0.0f) || (d.z == 0.0f);
+  }
+}
+
+template <bool EXACT_NAN>
+__device__ __forceinline__ bool slabHit(const vec3& o, const vec3& inv, float rayT, const float4& bmin, const float4& bmax,
+                                        float& tminOut) {
+  const float t1x = (bmin.x - o.x) * inv.x, t1y = (bmin.y - o.y) * inv.y, t1z = (bmin.z - o.z) * inv.z;
+  const float t2x = (bmax.x - o.x) * inv.x, t2y = (bmax.y - o.y) * inv.y, t2z = (bmax.z - o.z) * inv.z;
+  float tmin, tmax;
+  if (EXACT_NAN) {
+    tmin = pt::gmax(pt::gmax(pt::gmin(t1x, t2x), pt::gmin(t1y, t2y)), pt::gmin(t1z, t2z));
+    tmax = pt::gmin(pt::gmin(pt::gmax(t1x, t2x), pt::gmax(t1y, t2y)), pt::gmax(t1z, t2z));
+  } else {
+    tmin = vmax3(vmin(t1x, t2x), vmin(t1y, t2y), vmin(t1z, t2z));
+    tmax = vmin3(vmax(t1x, t2x), vmax(t1y, t2y), vmax(t1z, t2z));
+  }
+  tminOut = tmin;
+  return tmax >= tmin && tmin < rayT && tmax > 0.0f;
+}
+
 template <bool EXACT_NAN>
 __device__ __forceinline__ float slabTest(const vec3& o, const vec3& inv, float rayT, const float4& bmin,
                                           const float4& bmax) {
@@ -54,7 +107,11 @@ __device__ __forceinline__ float triangleTest(const vec3& o, const vec3& d, cons
   const vec3 h = pt::cross(d, edge2);
   const float a = pt::dot(edge1, h);
   const bool parallel = a > -1e-4f && a < 1e-4f;
-  const float f = 1.0f / a;
+  // f = 1.0f / a: lanes that go on have |a| >= 1e-4, so only the top of the range needs the guard
+  // (a rejected lane's f is never used)
+  float f;
+  if (PTX_FAST_RCP_TRI && __all(parallel || fabsf(a) < kRcpHi)) f = rcpNewton(a);
+  else f = 1.0f / a;
   const vec3 s = o - f4xyz(tri.v0);
   const float uu = f * pt::dot(s, h);
   const bool uOut = uu < 0.0f || uu > 1.0f;

@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
     bounces = 1u;
   }
   if (!gpuRender) {
-    fprintf(stderr, "-d 1: the CPU render path is test infrastructure in this repository (oracle/pt_oracle.c);\n"
+    fprintf(stderr, "-d 1: the CPU render path exists only as the test checker of this repository;\n"
                     "this binary renders on the GPU only and has no CPU fallback.\n");
     return EXIT_FAILURE;
   }

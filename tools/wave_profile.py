@@ -29,3 +29,9 @@ print(f"{'body':12s} {'iterations':>14s} {'frac of loop':>13s} {'lanes/iter':>11
 for k, n in enumerate(names):
     it, ln = buf[2 * k], buf[2 * k + 1]
     print(f"{n:12s} {it:14d} {it / max(iters, 1):13.3f} {ln / max(it, 1):11.2f} {ln:14d}")
+tn = ["shade+checks", "decode+issue", "wait (vmcnt/lgkmcnt)", "exit", "enter", "tri", "node", "merge"]
+tt = sum(buf[16 + k] for k in range(8))
+if tt:
+    print(f"\nwall-clock ticks per region, summed over waves (total {tt:.4g}; per loop iteration {tt / max(iters, 1):.0f})")
+    for k, n in enumerate(tn):
+        print(f"  {n:24s} {buf[16 + k] / tt:7.3f}   {buf[16 + k] / max(iters, 1):8.1f} ticks/iteration")
