@@ -12,7 +12,7 @@ divides, colour-grades and tonemaps.  The scene is resident in HBM before the ti
 RNG streams: the reference seeds one serial stream per pixel (gpuRender.cu:130), i.e. 1.2 M
 independent chains of 100 samples for this frame -- fewer than four per lane of an MI355X, so the
 chip idles through a long tail.  The same sample-slice construct that splits a frame over GPUs is
-therefore also used inside a GPU: --sub-streams S (default 10) gives every pixel S streams of
+therefore also used inside a GPU: --sub-streams S (default 25) gives every pixel S streams of
 100/S samples, each a work item of its own (ptx_params.sub_streams; parity against the sum of the
 oracle's streams in tests/test_gpu_radiance.py).  The frame with the reference's own seeding
 (S = 1, bit-compatible with gpuRender.cu's random sequence) is timed too and reported under
@@ -39,6 +39,11 @@ sys.path.insert(0, os.path.join(REPO, "path-tracer_amd", "py"))
 
 WIDTH, HEIGHT, SPP, BOUNCES, SCENE = 1500, 800, 100, 6, 1
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# What actually bounds the traversal loop: the vector memory path (address processing + L1), whose cost
+# is per load instruction and active lane.  A divergent 64-lane load costs ~45 cycles per CU whatever
+# its width (tools/ubench_gather2.hip, gpurun_out/ubench_gather3.txt: 180.8 cycles for 4 loads, L1
+# resident), i.e. 64 / 45.2 lane-accesses per cycle per CU.
+LANE_ACCESS_PEAK_G = 256 * (64 / 45.2) * 2.4  # G lane-accesses/s for 256 CUs at 2.4 GHz
 
 
 def algorithmic_bytes(st, width, height, hit_bytes=12):
@@ -72,7 +77,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sub-streams", type=int, default=10, help="RNG streams per pixel and GPU (1 = the reference's seeding)")
+    ap.add_argument("--no-reference-seeding", action="store_true", help="skip the extra frame with the reference's seeding")
+    ap.add_argument("--sub-streams", type=int, default=25, help="RNG streams per pixel and GPU (1 = the reference's seeding)")
     ap.add_argument("--spp", type=int, default=SPP, help=argparse.SUPPRESS)  # profiling runs only
     args = ap.parse_args()
 
@@ -138,7 +144,7 @@ def main():
     elapsed = tmax.item()
 
     ref_seed = None
-    if rank == 0 and world == 1 and args.sub_streams > 1:
+    if rank == 0 and world == 1 and args.sub_streams > 1 and not args.no_reference_seeding:
         # the same frame with the reference's seeding (one stream per pixel), one step, for the record
         p1 = ptamd.make_params(WIDTH, HEIGHT, spp=spp, max_bounces=BOUNCES, seed_mode=ptamd.SEED_REFERENCE_GPU)
         st1 = dscene.measure(scene.camera, p1)
@@ -158,6 +164,7 @@ def main():
             raise SystemExit("bench.py: rendered frame failed its sanity check")
         avg_kernel = sum(kernel_s) / len(kernel_s)
         alg = algorithmic_bytes(stats, WIDTH, HEIGHT)
+        lane_acc = 4 * stats.node_steps + 3 * stats.tri_tests + 4 * stats.inst_entries
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 --pmc passes
@@ -191,6 +198,12 @@ def main():
                 "frac": alg / avg_kernel / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "ptx::pathKernel<1, false, false>", "kernel_ms": avg_kernel * 1e3, "algorithmic_bytes": alg,
                 "node_steps": stats.node_steps, "tri_tests": stats.tri_tests, "inst_entries": stats.inst_entries,
+                # the kernel issues 4 16-byte lane-accesses per node step / instance entry and 3 per triangle test
+                "memory_path": {
+                    "bound": "vector memory path (lane-accesses: load instructions x active lanes)",
+                    "achieved": lane_acc / avg_kernel / 1e9, "peak": LANE_ACCESS_PEAK_G, "unit": "G lane-accesses/s",
+                    "frac": lane_acc / avg_kernel / 1e9 / LANE_ACCESS_PEAK_G,
+                },
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -18,8 +18,8 @@ run() { # name, timeout, args...
   echo "   rc=$rc" | tee -a $OUT/log.txt
   return $rc
 }
-run trace 400 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline || exit 1
-B="python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --spp $SPP"
+run trace 400 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-reference-seeding || exit 1
+B="python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-reference-seeding --spp $SPP"
 run pmc_sq1 300 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $OUT/pmc_sq1 -- $B || exit 1
 run pmc_sq2 300 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD --output-format csv -d $OUT/pmc_sq2 -- $B || exit 1
 run pmc_tcc 300 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/pmc_tcc -- $B || exit 1
