@@ -60,8 +60,9 @@ struct TriRec {     // 48 B
 
 struct InstXform {  // 64 B
   float4 row0, row1, row2;  // row r = (m[0][r], m[1][r], m[2][r], m[3][r]) of glm's column-major inverse model
-  uint32_t rootRef;         // BLAS root reference
-  uint32_t pad[3];
+  uint32_t rootRef;         // BLAS root reference (binary layout: NodePair index or leaf)
+  uint32_t wideRootRef;     // the same root in the wide layout (WideNode index or leaf)
+  uint32_t pad[2];
 };
 
 struct InstShade {  // 64 B
@@ -90,6 +91,7 @@ struct TextureRec {  // 16 B
 struct DeviceScene {
   const float4* arena;   // base of the one allocation; the three traversal arrays are also addressed
   uint32_t pairs16, tris16, inst16;  // from here, as offsets in 16-byte units (unified 64-byte fetch)
+  uint32_t wide16;                   // WideNode array of the radiance path (wide_bvh.hpp)
   const NodePair* pairs;
   const TriRec* tris;
   const InstXform* instXform;
@@ -103,6 +105,7 @@ struct DeviceScene {
   const float4* texels;
   const float4* environment;
   uint32_t tlasRootRef;
+  uint32_t tlasRootRefWide;  // the TLAS root in the wide layout
   uint32_t envWidth, envHeight;
 };
 

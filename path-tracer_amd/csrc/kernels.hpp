@@ -140,7 +140,7 @@ __device__ __forceinline__ void workPixel(const FrameConstants& fc, uint32_t w, 
   y = band * 8u + (r - cx * rows);
 }
 
-template <int MODE, bool STATS, bool RESOLVE>
+template <int MODE, bool STATS, bool WIDE>
 __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(DeviceScene sc, FrameConstants fc, uint32_t* workCounter,
                                                             void* __restrict__ outRaw, DeviceStats* stats,
                                                             uint32_t* stackOverflow) {
@@ -225,16 +225,9 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
           while (sample == 0u && live) {
             if (MODE == kModeRadiance && havePixel) {
               const uint32_t p = pix & 0x00FFFFFFu, k = pix >> 24;
-              if (RESOLVE) {  // one stream per pixel (host-checked)
-                const vec3 c = resolvePixel(sum, (float)fc.spp);
-                float* out = reinterpret_cast<float*>(outRaw);
-                out[3ull * p + 0] = c.x;
-                out[3ull * p + 1] = c.y;
-                out[3ull * p + 2] = c.z;
-              } else {  // plane k of the accumulation buffer: (sum, samples) of stream k
-                const uint32_t n = fc.sppBase + (k < fc.sppExtra ? 1u : 0u);
-                reinterpret_cast<float4*>(outRaw)[(size_t)k * nPixels + p] = make_float4(sum.x, sum.y, sum.z, (float)n);
-              }
+              // plane k of the accumulation buffer: (sum, samples) of stream k
+              const uint32_t n = fc.sppBase + (k < fc.sppExtra ? 1u : 0u);
+              reinterpret_cast<float4*>(outRaw)[(size_t)k * nPixels + p] = make_float4(sum.x, sum.y, sum.z, (float)n);
             }
             const uint32_t w = atomicAdd(workCounter, 1u);  // aggregated per wave by the compiler
             if (w >= totalWork) {
@@ -290,7 +283,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
           tlasLeaf = 0u;
           stk.lds[0] = kRefDone;  // slot 0: bottom-of-stack marker
           sp = 1u;
-          ref = sc.tlasRootRef;
+          ref = WIDE ? sc.tlasRootRefWide : sc.tlasRootRef;
           pending = true;
         } else {
           ref = kRefIdle;
@@ -326,7 +319,8 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       const uint32_t first = ref & (isTri ? 0x007FFFFFu : 0x00FFFFFFu);
       const uint32_t nPrim = (isTri ? ((ref >> 23) & 0x7Fu) : ((ref >> 24) & 0x3Fu)) + 1u;
 
-      const bool deep = __any(sp + 2u >= kLdsStack);  // wave-uniform; false almost always
+      // wave-uniform; false almost always (a wide step writes up to three slots above the top and a spare)
+      const bool deep = __any(sp + (WIDE ? 5u : 2u) >= kLdsStack);
       const uint32_t top = stackRead(stk, sp ? sp - 1u : 0u, deep);
 
       // Record fetch.  The loop is bound by the vector memory path, whose cost is per load instruction
@@ -337,7 +331,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       // path already serves as one access.)
       const bool fetch3 = isNode || isTri || isEnter;
       const bool fetch4 = isNode || isEnter;
-      const uint32_t off16 = isNode ? sc.pairs16 + ref * 4u : (isTri ? sc.tris16 + first * 3u : sc.inst16 + first * 4u);
+      const uint32_t off16 = isNode ? (WIDE ? sc.wide16 : sc.pairs16) + ref * 4u : (isTri ? sc.tris16 + first * 3u : sc.inst16 + first * 4u);
       const float4* rp = sc.arena + off16;
       float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0, r3 = r0;
       if (fetch3) { r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; }
@@ -346,6 +340,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       uint32_t newRef = ref;
       uint32_t pushVal = 0u;
       bool doPush = false, doPop = false;
+      uint32_t push2 = 0u, push3 = 0u, nPush = 0u;  // WIDE: a node step defers up to three children
       PTX_STAMP(1);  // decode, addresses, loads issued
       PTX_WAIT_ALL();
       PTX_STAMP(2);  // waiting for the record and the stack top
@@ -380,7 +375,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
         if (STATS) nInstEntries++;
         pushVal = kRefInstExit;
         doPush = true;
-        newRef = __float_as_uint(r3.x);  // InstXform::rootRef
+        newRef = __float_as_uint(WIDE ? r3.y : r3.x);  // InstXform::rootRef / wideRootRef
       }
       PTX_STAMP(4);
       PTX_MARK("TRI");
@@ -399,7 +394,22 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       }
       PTX_STAMP(5);
       PTX_MARK("NODE");
-      if (isNode) {
+      if (WIDE && isNode) {
+        // Four-wide node of the radiance path (wide_bvh.hpp): nearest hit child next, the others are
+        // deferred farthest first, so that they pop nearest first.
+        uint32_t sr[4];
+        uint32_t nHit;
+        if (__any(zeroDir)) nHit = wideStep<true>(o, inv, hit.t, r0, r1, r2, r3, sr);
+        else nHit = wideStep<false>(o, inv, hit.t, r0, r1, r2, r3, sr);
+        if (STATS) nNodeSteps++;
+        count += nHit;
+        doPop = nHit == 0u;
+        newRef = doPop ? top : sr[0];
+        nPush = doPop ? 0u : nHit - 1u;
+        // sr[i] (i >= 1) goes to slot sp + nHit - 1 - i; unused ones to the spare slot sp + 3
+        pushVal = sr[1]; push2 = sr[2]; push3 = sr[3];
+      }
+      if (!WIDE && isNode) {
         // Internal node (intersection.hpp:133-161 / :201-230): one 64-byte record holds both children.
         float t1, t2;
         bool h1, h2;
@@ -434,7 +444,20 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
 
       PTX_STAMP(6);
       PTX_MARK("MERGE");
-      if (steps) {
+      if (WIDE) {
+        if (steps) {
+          // the one deferred reference of the other bodies is "child 1 of 1"
+          if (!isNode) nPush = doPush ? 1u : 0u;
+          const uint32_t off1 = nPush >= 1u ? nPush - 1u : 3u, off2 = nPush >= 2u ? nPush - 2u : 3u, off3 = nPush >= 3u ? 0u : 3u;
+          stackWrite(stk, sp + off1, pushVal, deep);
+          if (__any(nPush >= 2u)) {  // wave-uniform
+            stackWrite(stk, sp + off2, push2, deep);
+            stackWrite(stk, sp + off3, push3, deep);
+          }
+          sp = sp + nPush - (doPop ? 1u : 0u);
+          ref = newRef;
+        }
+      } else if (steps) {
         stackWrite(stk, sp, pushVal, deep);
         sp = sp + (doPush ? 1u : 0u) - (doPop ? 1u : 0u);
         ref = newRef;

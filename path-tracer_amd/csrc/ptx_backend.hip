@@ -14,6 +14,7 @@
 
 #include "device_scene.hpp"
 #include "kernels.hpp"
+#include "wide_bvh.hpp"
 
 using namespace ptx;
 
@@ -121,6 +122,7 @@ struct ptx_scene {
   size_t arenaBytes = 0;
   DeviceScene dev{};
   uint32_t tlasDepth = 0, blasDepth = 0;
+  uint32_t wideStackBound = 0;  // 0: the wide layout is not used for this scene
   double uploadSeconds = 0;
   // per-handle scratch, grown on demand
   void* outBuf = nullptr;
@@ -214,7 +216,7 @@ int persistentGrid(ptx_scene* s, K kernel, uint32_t& blocks) {
 }
 
 template <typename K>
-int launchPath(ptx_scene* s, K kernel, const FrameConstants& fc, void* dOut, hipStream_t stream) {
+int launchPath(ptx_scene* s, K kernel, const FrameConstants& fc, void* dOut, hipStream_t stream, bool wide = false) {
   uint32_t blocks = 0;
   int rc = persistentGrid(s, kernel, blocks);
   if (rc) return rc;
@@ -222,7 +224,7 @@ int launchPath(ptx_scene* s, K kernel, const FrameConstants& fc, void* dOut, hip
   const uint32_t needed = (work + kBlockThreads - 1u) / kBlockThreads;
   if (blocks > needed) blocks = needed;
   // overflow area of the traversal stack: entries beyond the LDS part, [entry][thread]
-  const uint32_t bound = s->tlasDepth + s->blasDepth + 2u;
+  const uint32_t bound = wide ? s->wideStackBound : s->tlasDepth + s->blasDepth + 2u;
   const size_t deepEntries = bound > kLdsStack ? bound - kLdsStack : 0u;
   const size_t ovfBytes = (deepEntries ? deepEntries : 1u) * (size_t)blocks * kBlockThreads * sizeof(uint32_t);
   if (s->ovfBytes < ovfBytes) {
@@ -247,32 +249,37 @@ int launchCounts(ptx_scene* s, const FrameConstants& fc, uint32_t* dOut, hipStre
   return launchPath(s, pathKernel<kModeCounts, false, false>, fc, dOut, stream);
 }
 
+// PTX_WIDE=0 in the environment keeps the radiance path on the binary layout (A/B measurements).
+bool useWide(const ptx_scene* s) {
+  static const char* env = getenv("PTX_WIDE");
+  return s->wideStackBound != 0u && !(env && env[0] == '0');
+}
+
 int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool resolve, hipStream_t stream, bool stats) {
-  if (fc.subStreams > 1u) {
-    // every stream of a pixel is a work item of its own and writes its own plane; the planes are
-    // added in stream order afterwards (deterministic, unlike float atomics)
-    const uint32_t nPixels = fc.width * fc.height;
-    const size_t bytes = (size_t)fc.subStreams * nPixels * sizeof(float4);
-    if (s->planeBytes < bytes) {
-      if (s->dPlanes) HIP_TRY(hipFree(s->dPlanes));
-      s->dPlanes = nullptr;
-      s->planeBytes = 0;
-      HIP_TRY(hipMalloc((void**)&s->dPlanes, bytes));
-      s->planeBytes = bytes;
-    }
-    int rc = stats ? launchPath(s, pathKernel<kModeRadiance, true, false>, fc, s->dPlanes, stream)
-                   : launchPath(s, pathKernel<kModeRadiance, false, false>, fc, s->dPlanes, stream);
-    if (rc) return rc;
-    combineKernel<<<dim3((nPixels + 255u) / 256u), dim3(256), 0, stream>>>(s->dPlanes, fc.subStreams, nPixels, dOut, resolve);
-    HIP_TRY(hipGetLastError());
-    return PTX_OK;
+  const bool wide = useWide(s);
+  auto launch = [&](void* out) {
+    if (wide) return stats ? launchPath(s, pathKernel<kModeRadiance, true, true>, fc, out, stream, true)
+                           : launchPath(s, pathKernel<kModeRadiance, false, true>, fc, out, stream, true);
+    return stats ? launchPath(s, pathKernel<kModeRadiance, true, false>, fc, out, stream)
+                 : launchPath(s, pathKernel<kModeRadiance, false, false>, fc, out, stream);
+  };
+  if (fc.subStreams == 1u && !resolve) return launch(dOut);  // the kernel writes (sum, samples) itself
+  // every stream of a pixel is a work item of its own and writes its own plane; the planes are added in
+  // stream order afterwards (deterministic, unlike float atomics), and resolved if the caller wants pixels
+  const uint32_t nPixels = fc.width * fc.height;
+  const size_t bytes = (size_t)fc.subStreams * nPixels * sizeof(float4);
+  if (s->planeBytes < bytes) {
+    if (s->dPlanes) HIP_TRY(hipFree(s->dPlanes));
+    s->dPlanes = nullptr;
+    s->planeBytes = 0;
+    HIP_TRY(hipMalloc((void**)&s->dPlanes, bytes));
+    s->planeBytes = bytes;
   }
-  if (stats) {
-    if (resolve) return launchPath(s, pathKernel<kModeRadiance, true, true>, fc, dOut, stream);
-    return launchPath(s, pathKernel<kModeRadiance, true, false>, fc, dOut, stream);
-  }
-  if (resolve) return launchPath(s, pathKernel<kModeRadiance, false, true>, fc, dOut, stream);
-  return launchPath(s, pathKernel<kModeRadiance, false, false>, fc, dOut, stream);
+  int rc = launch(s->dPlanes);
+  if (rc) return rc;
+  combineKernel<<<dim3((nPixels + 255u) / 256u), dim3(256), 0, stream>>>(s->dPlanes, fc.subStreams, nPixels, dOut, resolve);
+  HIP_TRY(hipGetLastError());
+  return PTX_OK;
 }
 
 int kernelSeconds(ptx_scene* s, double* out) {
@@ -352,6 +359,26 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
     geomShade[g].vtxNormalBase = G.vtx_normal_offset;
     geomShade[g].vtxUvBase = G.vtx_uv_offset;
   }
+  // the same trees, four wide and quantised, for the radiance path (wide_bvh.hpp)
+  std::vector<WideNode> wideNodes;
+  WideInfo tlasWide;
+  std::vector<WideInfo> blasWide(d->geometry_count);
+  uint32_t blasWideDepth = 0;
+  {
+    std::string err = buildWideTree(d->tlas_nodes, d->tlas_node_count,
+                                    [&](const ptx_bvh_node& nd) { return makeTlasLeafRef(nd.left_first, nd.count); }, wideNodes, tlasWide);
+    for (uint32_t g = 0; g < d->geometry_count && err.empty(); g++) {
+      const ptx_geometry& G = d->geometries[g];
+      err = buildWideTree(d->blas_nodes + G.node_offset, G.node_count,
+                          [&](const ptx_bvh_node& nd) { return makeLeafRef(G.tri_offset + nd.left_first, nd.count); }, wideNodes, blasWide[g]);
+      if (blasWide[g].depth > blasWideDepth) blasWideDepth = blasWide[g].depth;
+    }
+    if (!err.empty()) return fail(PTX_EINVAL, "wide BVH: " + err);
+  }
+  // a wide step defers up to three children; + the two markers + the spare slots above the top
+  uint32_t wideStackBound = 3u * (tlasWide.depth + blasWideDepth) + 2u + 4u;
+  if (wideStackBound > kStackEntries) wideStackBound = 0u;  // radiance stays on the binary layout
+
   if (tlas.depth + blasDepth + 2u > kStackEntries) {  // sanity bound on the overflow area
     char buf[160];
     snprintf(buf, sizeof(buf), "BVH too deep for the traversal stack: TLAS depth %u + BLAS depth %u + 2 > %u", tlas.depth,
@@ -382,7 +409,8 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
     ix[i].row1 = make_float4(m[1], m[5], m[9], m[13]);
     ix[i].row2 = make_float4(m[2], m[6], m[10], m[14]);
     ix[i].rootRef = blas[I.geometry_id].rootRef;
-    ix[i].pad[0] = ix[i].pad[1] = ix[i].pad[2] = 0;
+    ix[i].wideRootRef = blasWide[I.geometry_id].rootRef;
+    ix[i].pad[0] = ix[i].pad[1] = 0;
     const float* nm = I.normal_matrix;
     is[i].row0 = make_float4(nm[0], nm[4], nm[8], nm[12]);
     is[i].row1 = make_float4(nm[1], nm[5], nm[9], nm[13]);
@@ -425,6 +453,7 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
   // ---- one arena, one allocation ----
   size_t cur = 0;
   const size_t oPairs = arenaReserve<NodePair>(cur, pairs.size() ? pairs.size() : 1);
+  const size_t oWide = arenaReserve<WideNode>(cur, wideNodes.size() ? wideNodes.size() : 1);
   const size_t oTris = arenaReserve<TriRec>(cur, tris.size());
   const size_t oIx = arenaReserve<InstXform>(cur, ix.size());
   const size_t oIs = arenaReserve<InstShade>(cur, is.size());
@@ -454,6 +483,7 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
     return bytes ? hipMemcpy(base + off, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
   };
   hipError_t errs[] = {
+      up(oWide, wideNodes.data(), wideNodes.size() * sizeof(WideNode)),
       up(oPairs, pairs.data(), pairs.size() * sizeof(NodePair)), up(oTris, tris.data(), tris.size() * sizeof(TriRec)),
       up(oIx, ix.data(), ix.size() * sizeof(InstXform)),         up(oIs, is.data(), is.size() * sizeof(InstShade)),
       up(oGs, geomShade.data(), geomShade.size() * sizeof(GeomShade)), up(oFn, faceN.data(), faceN.size() * sizeof(float4)),
@@ -471,6 +501,7 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
   DeviceScene& D = s->dev;
   D.arena = (const float4*)base;
   D.pairs16 = (uint32_t)(oPairs / 16);
+  D.wide16 = (uint32_t)(oWide / 16);
   D.tris16 = (uint32_t)(oTris / 16);
   D.inst16 = (uint32_t)(oIx / 16);
   D.pairs = (const NodePair*)(base + oPairs);
@@ -486,6 +517,8 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
   D.texels = (const float4*)(base + oTexels);
   D.environment = (const float4*)(base + oEnv);
   D.tlasRootRef = tlas.rootRef;
+  D.tlasRootRefWide = tlasWide.rootRef;
+  s->wideStackBound = wideStackBound;
   D.envWidth = d->env_width;
   D.envHeight = d->env_height;
   s->tlasDepth = tlas.depth;

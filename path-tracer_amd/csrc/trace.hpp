@@ -97,6 +97,83 @@ __device__ __forceinline__ float slabTest(const vec3& o, const vec3& inv, float 
   return (tmax >= tmin && tmin < rayT && tmax > 0.0f) ? tmin : FLT_MAX;
 }
 
+// One step on a WideNode (wide_bvh.hpp): up to four children, boxes as bytes in the parent's frame.
+// Returns how many children the ray hits (same acceptance as the slab test above: tmax >= tmin, tmin <
+// ray.t, tmax > 0) and their references in s[0..n), nearest first.  SAFE = false folds origin and
+// reciprocal direction into one fma per plane, t = byte * (scale * inv) + (frame - o) * inv; with an
+// infinite inv that form turns into inf - inf, so a wave holding a ray with a zero direction component
+// takes SAFE = true: plane = fma(byte, scale, frame), t = (plane - o) * inv, where the only NaN left is
+// 0 * inf (origin exactly on a plane of a slab the ray is parallel to), which v_min/v_max skip.
+template <int C>
+__device__ __forceinline__ float ubf(uint32_t x) { return (float)((x >> (8 * C)) & 0xFFu); }  // v_cvt_f32_ubyteC
+
+template <bool SAFE>
+__device__ __forceinline__ uint32_t wideStep(const vec3& o, const vec3& inv, float rayT, const float4& q0, const float4& q1, const float4& q2,
+                                             const float4& q3, uint32_t (&s)[4]) {
+  const uint32_t eb = __float_as_uint(q0.w);
+  const float sx = __uint_as_float((eb & 0xFFu) << 23), sy = __uint_as_float(((eb >> 8) & 0xFFu) << 23),
+              sz = __uint_as_float(((eb >> 16) & 0xFFu) << 23);
+  const uint32_t nKids = eb >> 24;
+  const uint32_t lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
+  const uint32_t hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
+  float key[4];
+  uint32_t nHit = 0;
+  if (SAFE) {
+    // general form: dequantise the plane, then the slab test of the binary path
+#define PTX_WIDE_CHILD(c)                                                                                              \
+  {                                                                                                                    \
+    const float t1x = (__builtin_fmaf(ubf<c>(lox), sx, q0.x) - o.x) * inv.x, t2x = (__builtin_fmaf(ubf<c>(hix), sx, q0.x) - o.x) * inv.x; \
+    const float t1y = (__builtin_fmaf(ubf<c>(loy), sy, q0.y) - o.y) * inv.y, t2y = (__builtin_fmaf(ubf<c>(hiy), sy, q0.y) - o.y) * inv.y; \
+    const float t1z = (__builtin_fmaf(ubf<c>(loz), sz, q0.z) - o.z) * inv.z, t2z = (__builtin_fmaf(ubf<c>(hiz), sz, q0.z) - o.z) * inv.z; \
+    const float tmin = vmax3(vmin(t1x, t2x), vmin(t1y, t2y), vmin(t1z, t2z));                                          \
+    const float tmax = vmin3(vmax(t1x, t2x), vmax(t1y, t2y), vmax(t1z, t2z));                                          \
+    const bool h = tmax >= tmin && tmin < rayT && tmax > 0.0f && (c < 2 || nKids > c);                                 \
+    key[c] = h ? tmin : __builtin_inff();                                                                              \
+    nHit += h ? 1u : 0u;                                                                                               \
+  }
+    PTX_WIDE_CHILD(0) PTX_WIDE_CHILD(1) PTX_WIDE_CHILD(2) PTX_WIDE_CHILD(3)
+#undef PTX_WIDE_CHILD
+  } else {
+    // Every direction component is finite and non-zero here.  t = byte * (scale * inv) + (frame - o) * inv
+    // is one fma per plane and monotone in the byte, so the sign of inv says which of lo / hi is the
+    // entry plane: one select per axis picks the dwords that hold the four children's entry and exit
+    // bytes, and no per-child min / max is needed.  The acceptance is widened to max(tmin, 0) <=
+    // min(tmax, ray.t): a superset of the slab test's, which the wide layout allows (wide_bvh.hpp).
+    const float ax = sx * inv.x, ay = sy * inv.y, az = sz * inv.z;
+    const float bx = (q0.x - o.x) * inv.x, by = (q0.y - o.y) * inv.y, bz = (q0.z - o.z) * inv.z;
+    const bool px = inv.x >= 0.0f, py = inv.y >= 0.0f, pz = inv.z >= 0.0f;
+    const uint32_t nx = px ? lox : hix, fx = px ? hix : lox;
+    const uint32_t ny = py ? loy : hiy, fy = py ? hiy : loy;
+    const uint32_t nz = pz ? loz : hiz, fz = pz ? hiz : loz;
+#define PTX_WIDE_CHILD(c)                                                                                              \
+  {                                                                                                                    \
+    const float tnx = __builtin_fmaf(ubf<c>(nx), ax, bx), tfx = __builtin_fmaf(ubf<c>(fx), ax, bx);                    \
+    const float tny = __builtin_fmaf(ubf<c>(ny), ay, by), tfy = __builtin_fmaf(ubf<c>(fy), ay, by);                    \
+    const float tnz = __builtin_fmaf(ubf<c>(nz), az, bz), tfz = __builtin_fmaf(ubf<c>(fz), az, bz);                    \
+    const float tmin = vmax(vmax3(tnx, tny, tnz), 0.0f);                                                               \
+    const float tmax = vmin(vmin3(tfx, tfy, tfz), rayT);                                                               \
+    const bool h = tmin <= tmax && (c < 2 || nKids > c);                                                               \
+    key[c] = h ? tmin : __builtin_inff();                                                                              \
+    nHit += h ? 1u : 0u;                                                                                               \
+  }
+    PTX_WIDE_CHILD(0) PTX_WIDE_CHILD(1) PTX_WIDE_CHILD(2) PTX_WIDE_CHILD(3)
+#undef PTX_WIDE_CHILD
+  }
+  s[0] = __float_as_uint(q3.x); s[1] = __float_as_uint(q3.y); s[2] = __float_as_uint(q3.z); s[3] = __float_as_uint(q3.w);
+  // five-comparator sorting network on (key, reference); misses carry +inf and end up last
+#define PTX_CSWAP(a, b)                                  \
+  {                                                      \
+    const bool sw = key[a] > key[b];                     \
+    const float ka = key[a], kb = key[b];                \
+    const uint32_t ra = s[a], rb = s[b];                 \
+    key[a] = sw ? kb : ka; key[b] = sw ? ka : kb;        \
+    s[a] = sw ? rb : ra;   s[b] = sw ? ra : rb;          \
+  }
+  PTX_CSWAP(0, 1) PTX_CSWAP(2, 3) PTX_CSWAP(0, 2) PTX_CSWAP(1, 3) PTX_CSWAP(1, 2)
+#undef PTX_CSWAP
+  return nHit;
+}
+
 // intersection.hpp:9-44 on a TriRec (edges precomputed on the host with the same subtractions).
 // Written without early returns: every lane evaluates the whole test and the reference's five
 // rejection conditions are combined at the end, each with the reference's own comparison (so a NaN

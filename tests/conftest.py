@@ -61,6 +61,13 @@ def scene1_small():
 @pytest.fixture(scope="session")
 def gpu_scenes(scene0, scene1, scene2):
     """ptx_create on cuda:0 for the three presets (GPU tests only)."""
+    # torch ships its own copy of the HIP runtime: when a test uses torch for device buffers it has to
+    # be loaded BEFORE libptx_backend.so pulls in /opt/rocm's, or torch finds no GPU ("No HIP GPUs")
+    try:
+        import torch  # noqa: F401
+        torch.cuda.is_available()
+    except ImportError:
+        pass
     devs = {0: ptamd.DeviceScene(scene0.desc_ptr), 1: ptamd.DeviceScene(scene1.desc_ptr),
             2: ptamd.DeviceScene(scene2.desc_ptr)}
     hosts = {0: scene0, 1: scene1, 2: scene2}
