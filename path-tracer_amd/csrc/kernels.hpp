@@ -38,10 +38,10 @@ namespace ptx {
 
 constexpr uint32_t kBlockThreads = 256;  // 4 waves
 #ifndef PTX_LDS_STACK
-#define PTX_LDS_STACK 24
+#define PTX_LDS_STACK 26
 #endif
 #ifndef PTX_MIN_WAVES
-#define PTX_MIN_WAVES 5
+#define PTX_MIN_WAVES 6
 #endif
 constexpr uint32_t kLdsStack = PTX_LDS_STACK;  // stack entries per lane kept in LDS (1 KB per entry per block)
 // Tunables (see DESIGN.md "Scheduling inside a wave").
@@ -319,8 +319,8 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       const uint32_t first = ref & (isTri ? 0x007FFFFFu : 0x00FFFFFFu);
       const uint32_t nPrim = (isTri ? ((ref >> 23) & 0x7Fu) : ((ref >> 24) & 0x3Fu)) + 1u;
 
-      // wave-uniform; false almost always (a wide step writes up to three slots above the top and a spare)
-      const bool deep = __any(sp + (WIDE ? 5u : 2u) >= kLdsStack);
+      // wave-uniform; false almost always (a wide step writes the three slots above the top)
+      const bool deep = __any(sp + (WIDE ? 4u : 2u) >= kLdsStack);
       const uint32_t top = stackRead(stk, sp ? sp - 1u : 0u, deep);
 
       // Record fetch.  The loop is bound by the vector memory path, whose cost is per load instruction
@@ -333,7 +333,10 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       const bool fetch4 = isNode || isEnter;
       const uint32_t off16 = isNode ? (WIDE ? sc.wide16 : sc.pairs16) + ref * 4u : (isTri ? sc.tris16 + first * 3u : sc.inst16 + first * 4u);
       const float4* rp = sc.arena + off16;
-      float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0, r3 = r0;
+      // lanes that fetch nothing never look at r0..r3: "any value" without the 16 moves of a zero fill
+      float4 r0, r1, r2, r3;
+      asm volatile("" : "=v"(r0.x), "=v"(r0.y), "=v"(r0.z), "=v"(r0.w), "=v"(r1.x), "=v"(r1.y), "=v"(r1.z), "=v"(r1.w));
+      asm volatile("" : "=v"(r2.x), "=v"(r2.y), "=v"(r2.z), "=v"(r2.w), "=v"(r3.x), "=v"(r3.y), "=v"(r3.z), "=v"(r3.w));
       if (fetch3) { r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; }
       if (fetch4) r3 = rp[3];
 
@@ -448,11 +451,14 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
         if (steps) {
           // the one deferred reference of the other bodies is "child 1 of 1"
           if (!isNode) nPush = doPush ? 1u : 0u;
-          const uint32_t off1 = nPush >= 1u ? nPush - 1u : 3u, off2 = nPush >= 2u ? nPush - 2u : 3u, off3 = nPush >= 3u ? 0u : 3u;
-          stackWrite(stk, sp + off1, pushVal, deep);
+          // slots sp, sp+1, sp+2 in stack order: farthest deferred child lowest, nearest on top (slots at
+          // or above the new top receive values that are never read)
+          const uint32_t v0 = nPush == 3u ? push3 : (nPush == 2u ? push2 : pushVal);
+          const uint32_t v1 = nPush == 3u ? push2 : pushVal;
+          stackWrite(stk, sp, v0, deep);
           if (__any(nPush >= 2u)) {  // wave-uniform
-            stackWrite(stk, sp + off2, push2, deep);
-            stackWrite(stk, sp + off3, push3, deep);
+            stackWrite(stk, sp + 1u, v1, deep);
+            stackWrite(stk, sp + 2u, pushVal, deep);
           }
           sp = sp + nPush - (doPop ? 1u : 0u);
           ref = newRef;

@@ -152,7 +152,7 @@ __device__ __forceinline__ uint32_t wideStep(const vec3& o, const vec3& inv, flo
     const float tnz = __builtin_fmaf(ubf<c>(nz), az, bz), tfz = __builtin_fmaf(ubf<c>(fz), az, bz);                    \
     const float tmin = vmax(vmax3(tnx, tny, tnz), 0.0f);                                                               \
     const float tmax = vmin(vmin3(tfx, tfy, tfz), rayT);                                                               \
-    const bool h = tmin <= tmax && (c < 2 || nKids > c);                                                               \
+    const bool h = tmin <= tmax; /* an empty slot (lo = 255, hi = 0) has entry > exit on every axis */                 \
     key[c] = h ? tmin : __builtin_inff();                                                                              \
     nHit += h ? 1u : 0u;                                                                                               \
   }

@@ -9,7 +9,7 @@ cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ff
        f"{REPO}/path-tracer_amd/csrc/ptx_backend.hip", "-o", f"{tmp}/k.s"] + sys.argv[1:]
 subprocess.check_call(cmd)
 text = open(f"{tmp}/k.s").read()
-m = re.search(r"^_ZN3ptx10pathKernelILi1ELb0ELb0E.*?:\n(.*?)s_endpgm", text, re.S | re.M)
+m = re.search(r"^_ZN3ptx10pathKernelILi1ELb0ELb" + ("1" if os.environ.get("ISA_WIDE") else "0") + r"E.*?:\n(.*?)s_endpgm", text, re.S | re.M)
 lines = m.group(1).splitlines()
 region = "PRE"
 # issue cost per wave64 instruction per SIMD, measured with tools/ubench_valu2.hip (gpurun_out/ubench_valu2.txt)
