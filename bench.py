@@ -196,7 +196,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": alg / avg_kernel / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg / avg_kernel / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "ptx::pathKernel<1, false, false>", "kernel_ms": avg_kernel * 1e3, "algorithmic_bytes": alg,
+                "kernel": "ptx::pathKernel<1, false, true>", "kernel_ms": avg_kernel * 1e3, "algorithmic_bytes": alg,
                 "node_steps": stats.node_steps, "tri_tests": stats.tri_tests, "inst_entries": stats.inst_entries,
                 # the kernel issues 4 16-byte lane-accesses per node step / instance entry and 3 per triangle test
                 "memory_path": {

@@ -14,7 +14,7 @@ s = json.loads(subprocess.check_output([sys.executable, os.path.join(here, "pmc_
 d = s["derived"]
 out = {
     "workload": f"scene1_1500x800_{spp}spp_6b",
-    "kernel": "ptx::pathKernel<1, false, false>",
+    "kernel": "ptx::pathKernel<1, false, true>",
     "hbm_bytes_per_launch": d["fetch_bytes_x2_corrected"] + d["write_bytes"],
     "fetch_size_raw_bytes": d["fetch_bytes_raw"], "fetch_correction": 2.0, "write_bytes": d["write_bytes"],
     "l2_hit_rate": d.get("l2_hit_rate"), "valu_lane_utilisation": d.get("valu_lane_utilisation"),
