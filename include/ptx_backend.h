@@ -205,6 +205,20 @@ int ptx_measure(ptx_scene* scene, const ptx_camera* camera, const ptx_params* pa
  * launch stream); synchronises that stream. */
 int ptx_last_kernel_seconds(ptx_scene* scene, double* seconds);
 
+/* Self-checks of two things the radiance path relies on (no counterpart in the reference).
+ *   ptx_check_wide_layout  : HOST ONLY, needs no GPU.  Builds the four-wide quantised re-layout of the
+ *                            scene's BVHs (what ptx_create builds for radiance calls) and verifies that
+ *                            every child's quantised box covers its exact box with the device's own
+ *                            arithmetic, and that every leaf of every tree is referenced exactly once.
+ *                            report[0] = wide nodes, [1] = child slots checked, [2] = slots whose
+ *                            quantised box does NOT cover (must be 0), [3] = leaves missing or
+ *                            duplicated (must be 0), [4] = deepest wide tree, [5] = binary nodes folded.
+ *   ptx_selftest_reciprocal: on `device`, compares the 3-instruction reciprocal used for ray
+ *                            directions with the IEEE 1.0f / x for EVERY float whose biased exponent is
+ *                            in [1, 252] (the guarded range); *mismatches must come back 0. */
+int ptx_check_wide_layout(const ptx_scene_desc* desc, uint64_t report[6]);
+int ptx_selftest_reciprocal(int device, uint64_t* mismatches);
+
 /* Replaces the frees at gpuRender.cu:289-310. */
 void ptx_destroy(ptx_scene* scene);
 

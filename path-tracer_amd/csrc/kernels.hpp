@@ -515,6 +515,19 @@ __global__ void __launch_bounds__(256) combineKernel(const float4* __restrict__ 
   }
 }
 
+// ptx_selftest_reciprocal: every float with biased exponent 1..252, both signs (2 * 252 * 2^23 values).
+__global__ void __launch_bounds__(256) reciprocalCheckKernel(unsigned long long* mismatches) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  unsigned long long bad = 0;
+  for (uint64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < 2ull * 252ull * (1ull << 23); i += stride) {
+    const uint32_t sign = (uint32_t)(i & 1ull) << 31;
+    const uint32_t mag = (uint32_t)(i >> 1) + (1u << 23);  // exponent field 1 .. 252
+    const float x = __uint_as_float(sign | mag);
+    if (__float_as_uint(rcpNewton(x)) != __float_as_uint(1.0f / x)) bad++;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
 // Tail of gpuRender.cu:158-169 on a summed accumulation buffer.
 __global__ void __launch_bounds__(256) resolveKernel(const float4* __restrict__ accum, uint32_t nPixels,
                                                      float* __restrict__ out) {

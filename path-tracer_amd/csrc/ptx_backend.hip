@@ -528,6 +528,112 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
   return PTX_OK;
 }
 
+int ptx_selftest_reciprocal(int device, uint64_t* mismatches) {
+  if (!mismatches) return fail(PTX_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(device));
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, sizeof(*d)));
+  hipError_t e = hipMemset(d, 0, sizeof(*d));
+  if (e == hipSuccess) {
+    reciprocalCheckKernel<<<dim3(4096), dim3(256)>>>(d);
+    e = hipGetLastError();
+  }
+  unsigned long long h = 0;
+  if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(e);
+  *mismatches = h;
+  return PTX_OK;
+}
+
+int ptx_check_wide_layout(const ptx_scene_desc* d, uint64_t report[6]) {
+  if (!d || !report || !d->tlas_nodes || !d->geometries || !d->blas_nodes) return fail(PTX_EINVAL, "null argument");
+  for (int i = 0; i < 6; i++) report[i] = 0;
+  // one pass per tree: build, then walk the wide nodes from the root
+  auto check = [&](const ptx_bvh_node* nodes, uint32_t n, bool isTlas, uint32_t primBase) -> int {
+    std::vector<WideNode> wide;
+    WideInfo info;
+    // leaves are referenced by their node index here, so that coverage can be checked against nodes[]
+    std::string err = buildWideTree(nodes, n, [&](const ptx_bvh_node& nd) { return kLeafFlag | (uint32_t)(&nd - nodes); }, wide, info);
+    (void)isTlas; (void)primBase;
+    if (!err.empty()) return fail(PTX_EINVAL, "wide BVH: " + err);
+    std::vector<uint32_t> leafSeen(n, 0);
+    uint64_t leaves = 0;
+    for (uint32_t i = 0; i < n; i++) leaves += nodes[i].count > 0;
+    if (info.depth > report[4]) report[4] = info.depth;
+    report[0] += wide.size();
+    report[5] += (n - leaves) - wide.size();
+    if ((int32_t)info.rootRef < 0) {  // single-leaf tree
+      leafSeen[info.rootRef & ~kLeafFlag]++;
+    }
+    // every wide node knows which binary nodes its children are only through the boxes: recompute the
+    // fold to pair child slots with binary nodes (same rule as the builder: its determinism is part of
+    // what is checked), then compare boxes
+    struct Item { uint32_t node, wideIndex; };
+    std::vector<Item> todo;
+    if ((int32_t)info.rootRef >= 0) todo.push_back({0u, info.rootRef});
+    while (!todo.empty()) {
+      const Item it = todo.back();
+      todo.pop_back();
+      const WideNode& w = wide[it.wideIndex];
+      const uint32_t eb = __builtin_bit_cast(uint32_t, w.q0.w);
+      const uint32_t nk = eb >> 24;
+      const float origin[3] = {w.q0.x, w.q0.y, w.q0.z};
+      const uint32_t lo[3] = {w.q1.x, w.q1.y, w.q1.z}, hi[3] = {w.q1.w, w.q2.x, w.q2.y};
+      const uint32_t refs[4] = {w.q3.x, w.q3.y, w.q3.z, w.q3.w};
+      // the builder's fold
+      uint32_t kids[4] = {nodes[it.node].left_first, nodes[it.node].left_first + 1u, 0, 0};
+      uint32_t cnt = 2;
+      while (cnt < 4) {
+        int best = -1;
+        float bestArea = -1.0f;
+        for (uint32_t c = 0; c < cnt; c++)
+          if (nodes[kids[c]].count == 0 && wide_detail::halfArea(nodes[kids[c]]) > bestArea) {
+            bestArea = wide_detail::halfArea(nodes[kids[c]]);
+            best = (int)c;
+          }
+        if (best < 0) break;
+        const uint32_t l = nodes[kids[best]].left_first;
+        kids[best] = l;
+        kids[cnt++] = l + 1u;
+      }
+      if (cnt != nk) { report[3]++; continue; }
+      for (uint32_t c = 0; c < nk; c++) {
+        report[1]++;
+        bool covers = true;
+        for (int a = 0; a < 3; a++) {
+          const float scale = __builtin_bit_cast(float, ((eb >> (8 * a)) & 0xFFu) << 23);
+          const float qlo = std::fmaf((float)((lo[a] >> (8 * c)) & 0xFFu), scale, origin[a]);
+          const float qhi = std::fmaf((float)((hi[a] >> (8 * c)) & 0xFFu), scale, origin[a]);
+          if (!(qlo <= nodes[kids[c]].aabb_min[a]) || !(qhi >= nodes[kids[c]].aabb_max[a])) covers = false;
+        }
+        if (!covers) report[2]++;
+        if (nodes[kids[c]].count > 0) {
+          if (refs[c] != (kLeafFlag | kids[c])) report[3]++;
+          else leafSeen[kids[c]]++;
+        } else if ((int32_t)refs[c] < 0 || refs[c] >= wide.size()) {
+          report[3]++;
+        } else {
+          todo.push_back({kids[c], refs[c]});
+        }
+      }
+    }
+    for (uint32_t i = 0; i < n; i++)
+      if (nodes[i].count > 0 && leafSeen[i] != 1u) report[3]++;
+    return PTX_OK;
+  };
+  if (d->tlas_node_count == 0 || (d->tlas_node_count & 1u) == 0u) return fail(PTX_EINVAL, "TLAS: node count must be odd and > 0");
+  int rc = check(d->tlas_nodes, d->tlas_node_count, true, 0u);
+  if (rc) return rc;
+  for (uint32_t g = 0; g < d->geometry_count; g++) {
+    const ptx_geometry& G = d->geometries[g];
+    if (G.node_count == 0 || (G.node_count & 1u) == 0u || (uint64_t)G.node_offset + G.node_count > d->blas_node_total)
+      return fail(PTX_EINVAL, "BLAS: bad node range");
+    if ((rc = check(d->blas_nodes + G.node_offset, G.node_count, false, G.tri_offset))) return rc;
+  }
+  return PTX_OK;
+}
+
 void ptx_destroy(ptx_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);

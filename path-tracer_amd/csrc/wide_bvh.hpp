@@ -106,10 +106,12 @@ std::string buildWideTree(const ptx_bvh_node* nodes, uint32_t n, LeafRef leafRef
     return w;
   };
   if (out.size() >= kLeafFlag) return "too many wide BVH nodes";
+  const size_t firstWide = out.size();
   info.rootRef = reserve(0, 1);
   while (!todo.empty()) {
     const Todo t = todo.back();
     todo.pop_back();
+    if (out.size() - firstWide > n) return "malformed node links (cycle)";  // a tree has fewer wide nodes than nodes
     if (t.depth > info.depth) info.depth = t.depth;
     const ptx_bvh_node& parent = nodes[t.node];
     // fold: start from the two children, replace the internal child with the largest box by its own

@@ -220,7 +220,7 @@ _backend = None
 BACKEND_SYMBOLS = [
     "ptx_device_count", "ptx_create", "ptx_render_counts", "ptx_render", "ptx_accumulate_device",
     "ptx_resolve_device", "ptx_counts_device", "ptx_measure", "ptx_last_kernel_seconds", "ptx_destroy",
-    "ptx_last_error", "ptx_version",
+    "ptx_last_error", "ptx_version", "ptx_check_wide_layout", "ptx_selftest_reciprocal",
 ]
 
 

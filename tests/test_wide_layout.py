@@ -1,0 +1,73 @@
+"""The four-wide quantised re-layout the radiance path traverses (path-tracer_amd/csrc/wide_bvh.hpp).
+
+CPU part: ptx_check_wide_layout rebuilds the layout on the host and verifies, with the device's own
+arithmetic (fmaf(byte, scale, origin)), that every child's quantised box covers the exact box of the
+binary node it stands for and that every leaf is referenced exactly once -- the two properties that make
+the wide traversal visit a superset of the binary traversal's leaves.  GPU part: the guarded reciprocal
+is bit-identical to IEEE division on its whole range, and the two layouts find the same hits."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ptamd
+
+
+def _report(scene):
+    rep = (C.c_uint64 * 6)()
+    lib = ptamd.backend_lib()
+    lib.ptx_check_wide_layout.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    rc = lib.ptx_check_wide_layout(scene.desc_ptr, rep)
+    assert rc == 0, lib.ptx_last_error()
+    return [int(v) for v in rep]
+
+
+@pytest.mark.parametrize("which", ["scene2", "scene1_small", "scene0"])
+def test_quantised_boxes_cover_and_every_leaf_is_kept(which, request):
+    scene = request.getfixturevalue(which)
+    nodes, slots, uncovered, bad_leaves, depth, folded = _report(scene)
+    assert nodes > 0 and slots >= 2 * nodes
+    assert uncovered == 0
+    assert bad_leaves == 0
+    assert folded > 0          # every other level really is folded away
+    assert slots <= 4 * nodes
+    assert 0 < depth < 64
+
+
+def test_malformed_tree_is_rejected_not_looped(scene2):
+    """A cycle in the node links must come back as an error (the builder bounds its own work)."""
+    d = scene2.desc
+    n = d.blas_node_total
+    nodes = (ptamd.BvhNode * n).from_address(C.addressof(d.blas_nodes.contents))
+    saved = nodes[1].left_first, nodes[1].count
+    try:
+        nodes[1].left_first, nodes[1].count = 1, 0   # node 1 becomes its own left child
+        rep = (C.c_uint64 * 6)()
+        lib = ptamd.backend_lib()
+        lib.ptx_check_wide_layout.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        assert lib.ptx_check_wide_layout(scene2.desc_ptr, rep) != 0
+    finally:
+        nodes[1].left_first, nodes[1].count = saved
+
+
+@pytest.mark.gpu
+def test_reciprocal_is_ieee_on_its_whole_range():
+    lib = ptamd.backend_lib()
+    lib.ptx_selftest_reciprocal.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
+    bad = C.c_uint64(123)
+    assert lib.ptx_selftest_reciprocal(0, C.byref(bad)) == 0, lib.ptx_last_error()
+    assert bad.value == 0
+
+
+@pytest.mark.gpu
+def test_wide_and_binary_layouts_count_the_same_rays(gpu_scenes):
+    """ptx_measure on the radiance path (wide layout): every ray of the binary-layout oracle is there
+    (same seeds, same paths) and node steps are roughly halved."""
+    import oracle_binding as ob
+    hosts, devs = gpu_scenes
+    p = ptamd.make_params(200, 120, spp=4, max_bounces=6)
+    st = devs[1].measure(hosts[1].camera, p)
+    _, st_ref = ob.render(hosts[1], p, seed_mode=ptamd.SEED_REFERENCE_GPU)
+    assert abs(int(st.rays) - int(st_ref.rays)) <= max(8, int(0.02 * st_ref.rays))
+    assert st.node_steps < 0.7 * st_ref.node_steps
+    assert abs(int(st.tri_tests) - int(st_ref.tri_tests)) <= 0.1 * st_ref.tri_tests
