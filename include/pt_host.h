@@ -49,6 +49,13 @@ uint32_t pth_heatmap_colour(const uint32_t* counts, uint32_t n_pixels, float* rg
 /* output.cpp:8-28: clamp, (uint8)(c*255.0), vertical flip, 24-bit BMP.  Returns 0 / -1. */
 int pth_write_bmp(const char* path, const float* rgb, uint32_t width, uint32_t height);
 
+/* The two halves of pth_write_bmp: the quantised, flipped, padded pixel array (what the device-side
+ * output stage of ptx_backend.h returns ready-made) and the 54-byte container around it.
+ * rows holds pth_bmp_row_bytes(width) * height bytes. */
+uint32_t pth_bmp_row_bytes(uint32_t width);
+void pth_quantise_rows(const float* rgb, uint32_t width, uint32_t height, unsigned char* rows);
+int pth_write_bmp_rows(const char* path, const unsigned char* rows, uint32_t width, uint32_t height);
+
 /* Small probes of host arithmetic for the tests (random.hpp:12-29, tiny_obj_loader.h:890-1027,
  * glm::inverse as used by mesh.cpp:26-29). */
 uint32_t pth_pcg_hash(uint32_t* state);

@@ -177,6 +177,21 @@ int ptx_render_counts(ptx_scene* scene, const ptx_camera* camera, const ptx_para
 int ptx_render(ptx_scene* scene, const ptx_camera* camera, const ptx_params* params,
                float* out_rgb, ptx_stats* stats /* may be NULL */);
 
+/* Device-side output stage: what main() and output.cpp do to the rendered image before the BMP
+ * container is written, done on the GPU so that 3 bytes per pixel come back instead of 12 (or 4).
+ *   ptx_render_counts_bgr8 : ptx_render_counts, then the heat-map colouring of main.cpp:363-374 (maximum
+ *                            over the frame, afmhot(count / max), black where count == 0) and the
+ *                            quantisation of output.cpp:13-23 (clamp to [0,1], (unsigned char)(c * 255.0));
+ *                            *max_count receives the frame's maximum ("Maximum BVH tests").
+ *   ptx_render_bgr8        : ptx_render, then the same quantisation.
+ * out_rows is the pixel array of a 24-bit BMP: image row 0 (the bottom scan line, as the kernel's
+ * rows are ordered) first, 3 bytes per pixel in B, G, R order, every row padded with zeros to row_bytes
+ * (>= 3 * width; a BMP wants a multiple of 4).  Bit-identical to the host path on the same image. */
+int ptx_render_counts_bgr8(ptx_scene* scene, const ptx_camera* camera, const ptx_params* params,
+                           uint8_t* out_rows, uint32_t row_bytes, uint32_t* max_count, ptx_stats* stats /* may be NULL */);
+int ptx_render_bgr8(ptx_scene* scene, const ptx_camera* camera, const ptx_params* params,
+                    uint8_t* out_rows, uint32_t row_bytes, ptx_stats* stats /* may be NULL */);
+
 /* Multi-GPU building blocks (no counterpart in the reference, which is single-GPU; BASELINE.json
  * asks for a sample-slice split with an RCCL reduce of float accumulation buffers).
  * d_accum / d_out are DEVICE pointers on the scene's device (e.g. a torch tensor's data_ptr):

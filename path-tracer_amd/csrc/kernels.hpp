@@ -30,6 +30,7 @@
 // path and the radiance path draws the same random numbers as the reference's GPU kernel.
 #pragma once
 
+#include "../host/colors.hpp"
 #include "device_scene.hpp"
 #include "shade.hpp"
 #include "trace.hpp"
@@ -513,6 +514,48 @@ __global__ void __launch_bounds__(256) combineKernel(const float4* __restrict__ 
   } else {
     reinterpret_cast<float4*>(out)[i] = a;
   }
+}
+
+// ---- device-side output stage (main.cpp:363-374, output.cpp:13-23) ----
+__global__ void __launch_bounds__(256) maxCountKernel(const uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ out) {
+  __shared__ uint32_t part[4];
+  uint32_t m = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = max(m, counts[i]);
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+  if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, max(max(part[0], part[1]), max(part[2], part[3])));
+}
+
+__device__ __forceinline__ uint32_t quantise8(float c) {  // output.cpp:19-21: clamp, float * double, truncated
+  const float v = pt::gclamp(c, 0.0f, 1.0f);
+  return (uint32_t)(unsigned char)((double)v * 255.0);
+}
+
+__device__ __forceinline__ void storeBgr(uint8_t* __restrict__ rows, uint32_t rowBytes, uint32_t width, uint32_t i, const vec3& c) {
+  const uint32_t y = i / width, x = i - y * width;
+  uint8_t* p = rows + (size_t)y * rowBytes + 3u * x;
+  p[0] = (uint8_t)quantise8(c.z);
+  p[1] = (uint8_t)quantise8(c.y);
+  p[2] = (uint8_t)quantise8(c.x);
+}
+
+__global__ void __launch_bounds__(256) heatmapBytesKernel(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ maxCount,
+                                                          uint32_t width, uint32_t nPixels, uint32_t rowBytes, uint8_t* __restrict__ rows) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nPixels) return;
+  const float inverseMax = 1.0f / (float)maxCount[0];  // main.cpp:364-369
+  const uint32_t c = counts[i];
+  vec3 col(0.0f);
+  if (c > 0u) col = pt::afmhot((float)c * inverseMax);
+  storeBgr(rows, rowBytes, width, i, col);
+}
+
+__global__ void __launch_bounds__(256) quantiseKernel(const float* __restrict__ rgb, uint32_t width, uint32_t nPixels, uint32_t rowBytes,
+                                                      uint8_t* __restrict__ rows) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nPixels) return;
+  storeBgr(rows, rowBytes, width, i, vec3(rgb[3ull * i], rgb[3ull * i + 1], rgb[3ull * i + 2]));
 }
 
 // ptx_selftest_reciprocal: every float with biased exponent 1..252, both signs (2 * 252 * 2^23 values).

@@ -135,6 +135,8 @@ struct ptx_scene {
   hipEvent_t evStart = nullptr, evStop = nullptr;
   hipStream_t lastStream = nullptr;
   bool timed = false;
+  uint8_t* dRows = nullptr;   // device-side output stage: the BMP pixel array
+  size_t rowsBytes = 0;
   float4* dPlanes = nullptr;  // per-stream accumulation planes of a sub-stream launch
   size_t planeBytes = 0;
 };
@@ -642,6 +644,7 @@ void ptx_destroy(ptx_scene* s) {
   if (s->dStats) (void)hipFree(s->dStats);
   if (s->dWorkCounter) (void)hipFree(s->dWorkCounter);
   if (s->dOverflow) (void)hipFree(s->dOverflow);
+  if (s->dRows) (void)hipFree(s->dRows);
   if (s->dPlanes) (void)hipFree(s->dPlanes);
   if (s->evStart) (void)hipEventDestroy(s->evStart);
   if (s->evStop) (void)hipEventDestroy(s->evStop);
@@ -704,6 +707,72 @@ int ptx_render(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, float
   if ((rc = ensureOut(s, bytes))) return rc;
   if ((rc = launchRadiance(s, fc, (float*)s->outBuf, true, nullptr, false))) return rc;
   HIP_TRY(hipMemcpy(out, s->outBuf, bytes, hipMemcpyDeviceToHost));
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->upload_s = s->uploadSeconds;
+    if ((rc = kernelSeconds(s, &stats->render_s))) return rc;
+  }
+  return PTX_OK;
+}
+
+namespace {
+int ensureRows(ptx_scene* s, const ptx_params* prm, uint32_t rowBytes, size_t& bytes) {
+  if ((uint64_t)rowBytes < 3ull * prm->width) return fail(PTX_EINVAL, "row_bytes < 3 * width");
+  bytes = (size_t)rowBytes * prm->height;
+  if (s->rowsBytes < bytes) {
+    if (s->dRows) HIP_TRY(hipFree(s->dRows));
+    s->dRows = nullptr;
+    s->rowsBytes = 0;
+    HIP_TRY(hipMalloc((void**)&s->dRows, bytes));
+    s->rowsBytes = bytes;
+  }
+  HIP_TRY(hipMemsetAsync(s->dRows, 0, bytes, nullptr));  // row padding
+  return PTX_OK;
+}
+}  // namespace
+
+int ptx_render_counts_bgr8(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, uint8_t* out, uint32_t rowBytes,
+                           uint32_t* maxCount, ptx_stats* stats) {
+  FrameConstants fc;
+  int rc = makeFrame(s, cam, prm, true, fc);
+  if (rc) return rc;
+  if (!out || !maxCount) return fail(PTX_EINVAL, "null output");
+  HIP_TRY(hipSetDevice(s->device));
+  const uint32_t n = prm->width * prm->height;
+  size_t bytes = 0;
+  if ((rc = ensureOut(s, (size_t)n * sizeof(uint32_t)))) return rc;
+  if ((rc = ensureRows(s, prm, rowBytes, bytes))) return rc;
+  if ((rc = launchCounts(s, fc, (uint32_t*)s->outBuf, nullptr, false))) return rc;
+  uint32_t* dMax = s->dWorkCounter + 8;  // the work counter's allocation has room; launches clear only word 0
+  HIP_TRY(hipMemsetAsync(dMax, 0, sizeof(uint32_t), nullptr));
+  const uint32_t blocks = (n + 255u) / 256u;
+  maxCountKernel<<<dim3(blocks < 1024u ? blocks : 1024u), dim3(256)>>>((const uint32_t*)s->outBuf, n, dMax);
+  heatmapBytesKernel<<<dim3(blocks), dim3(256)>>>((const uint32_t*)s->outBuf, dMax, prm->width, n, rowBytes, s->dRows);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, s->dRows, bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(maxCount, dMax, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->upload_s = s->uploadSeconds;
+    if ((rc = kernelSeconds(s, &stats->render_s))) return rc;
+  }
+  return PTX_OK;
+}
+
+int ptx_render_bgr8(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, uint8_t* out, uint32_t rowBytes, ptx_stats* stats) {
+  FrameConstants fc;
+  int rc = makeFrame(s, cam, prm, false, fc);
+  if (rc) return rc;
+  if (!out) return fail(PTX_EINVAL, "null output");
+  HIP_TRY(hipSetDevice(s->device));
+  const uint32_t n = prm->width * prm->height;
+  size_t bytes = 0;
+  if ((rc = ensureOut(s, (size_t)n * 3u * sizeof(float)))) return rc;
+  if ((rc = ensureRows(s, prm, rowBytes, bytes))) return rc;
+  if ((rc = launchRadiance(s, fc, (float*)s->outBuf, true, nullptr, false))) return rc;
+  quantiseKernel<<<dim3((n + 255u) / 256u), dim3(256)>>>((const float*)s->outBuf, prm->width, n, rowBytes, s->dRows);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, s->dRows, bytes, hipMemcpyDeviceToHost));
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     stats->upload_s = s->uploadSeconds;

@@ -83,6 +83,12 @@ int pth_write_bmp(const char* path, const float* rgb, uint32_t w, uint32_t h) {
   return writeBmp(path, rgb, w, h) ? 0 : -1;
 }
 
+uint32_t pth_bmp_row_bytes(uint32_t w) { return bmpRowBytes(w); }
+void pth_quantise_rows(const float* rgb, uint32_t w, uint32_t h, unsigned char* rows) { quantiseRows(rgb, w, h, rows); }
+int pth_write_bmp_rows(const char* path, const unsigned char* rows, uint32_t w, uint32_t h) {
+  return writeBmpRows(path, rows, w, h) ? 0 : -1;
+}
+
 uint32_t pth_pcg_hash(uint32_t* state) { return pcg_hash(*state); }
 float pth_random_float(uint32_t* state) { return getRandomFloat(*state); }
 int pth_parse_decimal(const char* text, double* out) { return parseDecimal(text, text + strlen(text), out) ? 0 : -1; }

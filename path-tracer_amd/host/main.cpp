@@ -87,18 +87,32 @@ int main(int argc, char** argv) {
   getScene(sampleScene, assets, scene, geometryPool, materialPool, camera, info);
   Image environment = getEnvironment(assets, info);
 
-  renderGPU(scene, geometryPool, materialPool, camera, image, environment, samples, (int)bounces, renderBVH);
-
-  if (renderBVH) {  // main.cpp:363-374
-    std::vector<uint32_t> counts(image.data.size());
-    for (size_t i = 0; i < counts.size(); i++) counts[i] = (uint32_t)image.data[i].x;
-    uint32_t mx = heatmapColour(counts.data(), (uint32_t)counts.size(), reinterpret_cast<float*>(image.data.data()));
-    printf("Maximum BVH tests: %u\n", mx);
-  }
-
-  if (!writeBmp("output.bmp", reinterpret_cast<const float*>(image.data.data()), image.width, image.height)) {
-    fprintf(stderr, "cannot write output.bmp\n");
-    return EXIT_FAILURE;
+  // The output stage (heat-map colouring, clamp, 8-bit quantise, flip: main.cpp:363-374, output.cpp:13-23)
+  // runs on the device by default; PT_HOST_OUTPUT=1 takes the reference-shaped route through renderGPU
+  // and the host functions (same bytes in output.bmp, 4x the PCIe traffic).
+  const char* hostOutput = getenv("PT_HOST_OUTPUT");
+  if (hostOutput && hostOutput[0] == '1') {
+    renderGPU(scene, geometryPool, materialPool, camera, image, environment, samples, (int)bounces, renderBVH);
+    if (renderBVH) {  // main.cpp:363-374
+      std::vector<uint32_t> counts(image.data.size());
+      for (size_t i = 0; i < counts.size(); i++) counts[i] = (uint32_t)image.data[i].x;
+      uint32_t mx = heatmapColour(counts.data(), (uint32_t)counts.size(), reinterpret_cast<float*>(image.data.data()));
+      printf("Maximum BVH tests: %u\n", mx);
+    }
+    if (!writeBmp("output.bmp", reinterpret_cast<const float*>(image.data.data()), image.width, image.height)) {
+      fprintf(stderr, "cannot write output.bmp\n");
+      return EXIT_FAILURE;
+    }
+  } else {
+    std::vector<unsigned char> rows;
+    uint32_t maxTests = 0;
+    renderGPURows(scene, geometryPool, materialPool, camera, width, height, environment, samples, (int)bounces, renderBVH, rows,
+                  maxTests);
+    if (renderBVH) printf("Maximum BVH tests: %u\n", maxTests);
+    if (!writeBmpRows("output.bmp", rows.data(), width, height)) {
+      fprintf(stderr, "cannot write output.bmp\n");
+      return EXIT_FAILURE;
+    }
   }
   printf("Output result to output.bmp\n");
   return EXIT_SUCCESS;

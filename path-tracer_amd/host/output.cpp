@@ -20,19 +20,12 @@ uint32_t heatmapColour(const uint32_t* counts, uint32_t n, float* rgb) {
   return mx;
 }
 
-bool writeBmp(const std::string& path, const float* rgb, uint32_t W, uint32_t H) {
-  const uint32_t rowBytes = (W * 3u + 3u) & ~3u;
-  const uint32_t dataBytes = rowBytes * H;
-  std::vector<unsigned char> file(54 + dataBytes, 0);
-  auto put16 = [&](size_t o, uint32_t v) { file[o] = v & 255; file[o + 1] = (v >> 8) & 255; };
-  auto put32 = [&](size_t o, uint32_t v) { put16(o, v & 0xFFFF); put16(o + 2, v >> 16); };
-  file[0] = 'B'; file[1] = 'M';
-  put32(2, 54 + dataBytes); put32(10, 54);
-  put32(14, 40); put32(18, W); put32(22, H); put16(26, 1); put16(28, 24); put32(34, dataBytes);
+void quantiseRows(const float* rgb, uint32_t W, uint32_t H, unsigned char* rows) {
+  const uint32_t rowBytes = bmpRowBytes(W);
   // BMP stores bottom row first, which is image row 0 here; output.cpp:13-23 flips rows to feed a
   // top-down writer, so the file content is the same.
   for (uint32_t y = 0; y < H; y++) {
-    unsigned char* row = &file[54 + (size_t)rowBytes * y];
+    unsigned char* row = rows + (size_t)rowBytes * y;
     for (uint32_t x = 0; x < W; x++) {
       const float* p = &rgb[3 * ((size_t)y * W + x)];
       unsigned char q[3];
@@ -42,12 +35,30 @@ bool writeBmp(const std::string& path, const float* rgb, uint32_t W, uint32_t H)
       }
       row[3 * x + 0] = q[2]; row[3 * x + 1] = q[1]; row[3 * x + 2] = q[0];  // BGR
     }
+    for (uint32_t k = 3u * W; k < rowBytes; k++) row[k] = 0;
   }
+}
+
+bool writeBmpRows(const std::string& path, const unsigned char* rows, uint32_t W, uint32_t H) {
+  const uint32_t rowBytes = bmpRowBytes(W);
+  const uint32_t dataBytes = rowBytes * H;
+  unsigned char head[54] = {0};
+  auto put16 = [&](size_t o, uint32_t v) { head[o] = v & 255; head[o + 1] = (v >> 8) & 255; };
+  auto put32 = [&](size_t o, uint32_t v) { put16(o, v & 0xFFFF); put16(o + 2, v >> 16); };
+  head[0] = 'B'; head[1] = 'M';
+  put32(2, 54 + dataBytes); put32(10, 54);
+  put32(14, 40); put32(18, W); put32(22, H); put16(26, 1); put16(28, 24); put32(34, dataBytes);
   FILE* f = fopen(path.c_str(), "wb");
   if (!f) return false;
-  bool ok = fwrite(file.data(), 1, file.size(), f) == file.size();
+  bool ok = fwrite(head, 1, 54, f) == 54 && fwrite(rows, 1, dataBytes, f) == dataBytes;
   fclose(f);
   return ok;
+}
+
+bool writeBmp(const std::string& path, const float* rgb, uint32_t W, uint32_t H) {
+  std::vector<unsigned char> rows((size_t)bmpRowBytes(W) * H);
+  quantiseRows(rgb, W, H, rows.data());
+  return writeBmpRows(path, rows.data(), W, H);
 }
 
 }  // namespace pt

@@ -131,6 +131,12 @@ def host_lib():
         lib.pth_heatmap_colour.restype = C.c_uint32
         lib.pth_write_bmp.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
         lib.pth_write_bmp.restype = C.c_int
+        lib.pth_bmp_row_bytes.argtypes = [C.c_uint32]
+        lib.pth_bmp_row_bytes.restype = C.c_uint32
+        lib.pth_quantise_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        lib.pth_quantise_rows.restype = None
+        lib.pth_write_bmp_rows.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.pth_write_bmp_rows.restype = C.c_int
         lib.pth_pcg_hash.argtypes = [C.POINTER(C.c_uint32)]
         lib.pth_pcg_hash.restype = C.c_uint32
         lib.pth_random_float.argtypes = [C.POINTER(C.c_uint32)]
@@ -205,6 +211,15 @@ def heatmap_colour(counts):
     return rgb, mx
 
 
+def quantise_rows(rgb):
+    """Host output stage: (H, W, 3) float image -> BMP pixel array (H, row_bytes) uint8."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w = rgb.shape[:2]
+    rows = np.empty((h, host_lib().pth_bmp_row_bytes(w)), dtype=np.uint8)
+    host_lib().pth_quantise_rows(rgb.ctypes.data, w, h, rows.ctypes.data)
+    return rows
+
+
 def write_bmp(path, rgb):
     rgb = np.ascontiguousarray(rgb, dtype=np.float32)
     h, w = rgb.shape[:2]
@@ -220,7 +235,8 @@ _backend = None
 BACKEND_SYMBOLS = [
     "ptx_device_count", "ptx_create", "ptx_render_counts", "ptx_render", "ptx_accumulate_device",
     "ptx_resolve_device", "ptx_counts_device", "ptx_measure", "ptx_last_kernel_seconds", "ptx_destroy",
-    "ptx_last_error", "ptx_version", "ptx_check_wide_layout", "ptx_selftest_reciprocal",
+    "ptx_last_error", "ptx_version", "ptx_check_wide_layout", "ptx_selftest_reciprocal", "ptx_render_counts_bgr8",
+    "ptx_render_bgr8",
 ]
 
 
@@ -243,6 +259,9 @@ def backend_lib():
         lib.ptx_counts_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, vp]
         lib.ptx_measure.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), C.c_int, C.POINTER(Stats)]
         lib.ptx_last_kernel_seconds.argtypes = [vp, C.POINTER(C.c_double)]
+        lib.ptx_render_counts_bgr8.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.c_uint32, C.POINTER(C.c_uint32),
+                                               C.POINTER(Stats)]
+        lib.ptx_render_bgr8.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.c_uint32, C.POINTER(Stats)]
         lib.ptx_destroy.argtypes = [vp]
         lib.ptx_destroy.restype = None
         lib.ptx_last_error.restype = C.c_char_p
@@ -295,6 +314,22 @@ class DeviceScene:
         _check(backend_lib().ptx_render(self._h, C.byref(camera), C.byref(params), out.ctypes.data, C.byref(st)),
                "ptx_render")
         return out, st
+
+    def render_counts_bgr8(self, camera, params):
+        """Device-side output stage of the heat map: (rows (H, row_bytes) uint8, maximum count, stats)."""
+        rows = np.empty((params.height, host_lib().pth_bmp_row_bytes(params.width)), dtype=np.uint8)
+        st = Stats()
+        mx = C.c_uint32()
+        _check(backend_lib().ptx_render_counts_bgr8(self._h, C.byref(camera), C.byref(params), rows.ctypes.data_as(C.c_void_p),
+                                                    rows.shape[1], C.byref(mx), C.byref(st)), "ptx_render_counts_bgr8")
+        return rows, mx.value, st
+
+    def render_bgr8(self, camera, params):
+        rows = np.empty((params.height, host_lib().pth_bmp_row_bytes(params.width)), dtype=np.uint8)
+        st = Stats()
+        _check(backend_lib().ptx_render_bgr8(self._h, C.byref(camera), C.byref(params), rows.ctypes.data_as(C.c_void_p),
+                                             rows.shape[1], C.byref(st)), "ptx_render_bgr8")
+        return rows, st
 
     def accumulate_device(self, camera, params, d_accum_ptr, stream=None):
         _check(backend_lib().ptx_accumulate_device(self._h, C.byref(camera), C.byref(params), d_accum_ptr, stream),
