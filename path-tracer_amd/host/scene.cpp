@@ -2,6 +2,8 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <thread>
 
 #include "sah_builder.hpp"
 
@@ -14,6 +16,16 @@ void permute(std::vector<T>& values, const std::vector<uint>& order, uint group 
   for (size_t i = 0; i < order.size(); i++)
     for (uint j = 0; j < group; j++) out[size_t(group) * i + j] = values[size_t(group) * order[i] + j];
   values.swap(out);
+}
+// Threads of the BVH builder: PT_BUILD_THREADS, else the machine's cores, at most 16 (the tree does not
+// depend on it: sah_builder.hpp).
+uint buildThreads() {
+  if (const char* e = getenv("PT_BUILD_THREADS")) {
+    int v = atoi(e);
+    if (v >= 1) return (uint)(v > 64 ? 64 : v);
+  }
+  uint hw = std::thread::hardware_concurrency();
+  return hw == 0 ? 1u : (hw > 16u ? 16u : hw);
 }
 double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -35,7 +47,7 @@ Geometry::Geometry(std::vector<Triangle> prims, VertexAttributes attrs)
     hi[i] = primitives[i].getMax();
     cen[i] = primitives[i].centroid;
   }
-  BuildResult built = buildBVH(BuildInput{lo.data(), hi.data(), cen.data(), n});
+  BuildResult built = buildBVHParallel(BuildInput{lo.data(), hi.data(), cen.data(), n}, buildThreads());
   bvh = std::move(built.nodes);
   bvhDepth = built.maxDepth;
   maxLeafSize = built.maxLeafSize;
@@ -109,7 +121,7 @@ void Scene::completeScene() {
     hi[i] = meshes[i].getMax();
     cen[i] = meshes[i].centroid;
   }
-  BuildResult built = buildBVH(BuildInput{lo.data(), hi.data(), cen.data(), n});
+  BuildResult built = buildBVHParallel(BuildInput{lo.data(), hi.data(), cen.data(), n}, buildThreads());
   tlas = std::move(built.nodes);
   tlasDepth = built.maxDepth;
   maxLeafSize = built.maxLeafSize;

@@ -149,3 +149,21 @@ def test_heatmap_colour_and_bmp(tmp_path):
     assert row0[0:3] == bytes([0, 0, 255])   # BGR, bottom row first
     row1 = raw[54 + 12:54 + 12 + 9]
     assert row1[6:9] == bytes([255, 127, 0])
+
+
+def test_parallel_builder_makes_the_identical_tree(monkeypatch):
+    """the multi-threaded SAH builder (sah_builder.hpp:buildBVHParallel) must produce the
+    serial builder's tree bit for bit -- node boxes, numbering, leaf ranges and primitive order -- because
+    the `-a` heat map counts tests on exactly that tree."""
+    import numpy as np
+    built = {}
+    for threads in ("1", "8", "5"):
+        monkeypatch.setenv("PT_BUILD_THREADS", threads)
+        s = ptamd.HostScene(1, scatter_instances=50)   # 505,848-triangle BLAS: the parallel path
+        built[threads] = (s.blas_nodes.copy(), s.triangles.copy(), s.tlas_nodes.copy(), s.info.blas_build_s)
+        s.close()
+    for threads in ("8", "5"):
+        assert np.array_equal(built["1"][0], built[threads][0])
+        assert np.array_equal(built["1"][1], built[threads][1])
+        assert np.array_equal(built["1"][2], built[threads][2])
+    assert built["1"][0].shape[0] > 500000
