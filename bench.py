@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--no-reference-seeding", action="store_true", help="skip the extra frame with the reference's seeding")
     ap.add_argument("--sub-streams", type=int, default=25, help="RNG streams per pixel and GPU (1 = the reference's seeding)")
     ap.add_argument("--spp", type=int, default=SPP, help=argparse.SUPPRESS)  # profiling runs only
+    # rehearsal of the N > 1 path on a box with one GPU: every rank on cuda:0, buffers reduced through gloo
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     import torch
@@ -95,10 +97,31 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def reduce_sum_to_root(t):
+        if args.rehearse_on_one_gpu:  # gloo has no device tensors
+            h = t.cpu()
+            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: W*H*4 floats, once per frame
+
+    def all_reduce(t, op):
+        if args.rehearse_on_one_gpu:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
 
     spp = args.spp
     scene = ptamd.HostScene(SCENE)  # replicated on every GPU
@@ -113,7 +136,7 @@ def main():
         stream = torch.cuda.current_stream().cuda_stream
         dscene.accumulate_device(scene.camera, params, accum.data_ptr(), stream)
         if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: W*H*4 floats, once per frame
+            reduce_sum_to_root(accum)
         if rank == 0:
             dscene.resolve_device(accum.data_ptr(), WIDTH, HEIGHT, out.data_ptr(), stream)
 
@@ -138,8 +161,8 @@ def main():
     rays = torch.tensor([float(stats.rays)], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        all_reduce(rays, dist.ReduceOp.SUM)
+        all_reduce(tmax, dist.ReduceOp.MAX)
     total_rays = rays.item()
     elapsed = tmax.item()
 
