@@ -124,7 +124,10 @@ def main():
             dist.all_reduce(t, op=op)
 
     spp = args.spp
-    scene = ptamd.HostScene(SCENE)  # replicated on every GPU
+    # replicated on every GPU; the flattened arrays come from the on-disk cache when an earlier run (or
+    # another rank) on this machine has built them (pt_host.h: pth_scene_create_cached)
+    import tempfile
+    scene = ptamd.HostScene(SCENE, cache_dir=os.path.join(tempfile.gettempdir(), "ptx_scene_cache"))
     dscene = ptamd.DeviceScene(scene.desc_ptr, device=local_rank)
     params = ptamd.make_params(WIDTH, HEIGHT, spp=spp, max_bounces=BOUNCES, seed_mode=ptamd.SEED_STREAM,
                                part_index=rank, part_count=world, sub_streams=args.sub_streams)

@@ -37,6 +37,15 @@ typedef struct pth_info {
 int pth_scene_create(int preset, const char* models_dir, const char* env_path,
                      uint32_t scatter_instances, uint32_t sky_width, uint32_t sky_height,
                      pth_scene** out);
+/* The same, through an on-disk cache of the FLATTENED scene: the key is a hash of the
+ * preset, its parameters and the CONTENT of every asset file the preset reads (or the stand-in
+ * generator's version when a file is absent); a hit skips asset parsing, the BVH builds and the
+ * flattening and hands back byte-identical arrays.  cache_dir is created if needed; *cache_hit
+ * (may be NULL) tells what happened.  A cache file that is damaged or was written by another
+ * format version is ignored and rewritten. */
+int pth_scene_create_cached(int preset, const char* models_dir, const char* env_path,
+                            uint32_t scatter_instances, uint32_t sky_width, uint32_t sky_height,
+                            const char* cache_dir, int* cache_hit, pth_scene** out);
 const ptx_scene_desc* pth_scene_desc(const pth_scene* s);
 void pth_scene_camera(const pth_scene* s, ptx_camera* out);
 void pth_scene_info(const pth_scene* s, pth_info* out);

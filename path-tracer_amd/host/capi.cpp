@@ -1,6 +1,10 @@
 // C entry points of the host scene pipeline (include/pt_host.h).
 #include "../../include/pt_host.h"
 
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
 #include <cstring>
 #include <string>
 
@@ -21,6 +25,10 @@ struct pth_scene {
   Image environment;
   SceneInfo info;
   FlatScene flat;
+  // a scene that came out of the cache has only the flattened arrays
+  bool fromCache = false;
+  ptx_camera cachedCamera{};
+  pth_info cachedInfo{};
 };
 
 static thread_local std::string g_err;
@@ -54,9 +62,13 @@ int pth_scene_create(int preset, const char* models_dir, const char* env_path, u
 
 const ptx_scene_desc* pth_scene_desc(const pth_scene* s) { return &s->flat.desc; }
 
-void pth_scene_camera(const pth_scene* s, ptx_camera* out) { *out = toPtxCamera(s->camera); }
+void pth_scene_camera(const pth_scene* s, ptx_camera* out) { *out = s->fromCache ? s->cachedCamera : toPtxCamera(s->camera); }
 
 void pth_scene_info(const pth_scene* s, pth_info* o) {
+  if (s->fromCache) {
+    *o = s->cachedInfo;
+    return;
+  }
   memset(o, 0, sizeof(*o));
   const Geometry& g = *s->geometryPool[0];
   o->triangles_per_mesh = (uint32_t)g.primitives.size();
@@ -74,6 +86,151 @@ void pth_scene_info(const pth_scene* s, pth_info* o) {
 }
 
 void pth_scene_destroy(pth_scene* s) { delete s; }
+
+}  // extern "C"
+
+// ---- flattened-scene cache -------------------------------------------------------------------
+namespace {
+constexpr char kCacheMagic[8] = {'P', 'T', 'X', 'F', 'L', 'A', 'T', '3'};  // bump the digit with the format
+
+uint64_t fnv(uint64_t h, const void* data, size_t n) {
+  const unsigned char* p = (const unsigned char*)data;
+  for (size_t i = 0; i < n; i++) {
+    h ^= p[i];
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+uint64_t fnvFile(uint64_t h, const std::string& path, const char* absentTag) {
+  h = fnv(h, path.data() + (path.find_last_of('/') == std::string::npos ? 0 : path.find_last_of('/') + 1),
+          path.size() - (path.find_last_of('/') == std::string::npos ? 0 : path.find_last_of('/') + 1));
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return fnv(h, absentTag, strlen(absentTag));
+  std::vector<unsigned char> buf(1 << 20);
+  size_t got;
+  uint64_t total = 0;
+  while ((got = fread(buf.data(), 1, buf.size(), f)) > 0) {
+    h = fnv(h, buf.data(), got);
+    total += got;
+  }
+  fclose(f);
+  return fnv(h, &total, sizeof(total));
+}
+
+template <typename T>
+bool putVec(FILE* f, const std::vector<T>& v) {
+  uint64_t n = v.size();
+  return fwrite(&n, sizeof(n), 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
+}
+template <typename T>
+bool getVec(FILE* f, std::vector<T>& v, uint64_t limitBytes) {
+  uint64_t n = 0;
+  if (fread(&n, sizeof(n), 1, f) != 1 || n * sizeof(T) > limitBytes) return false;
+  v.resize(n);
+  return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+}
+
+template <typename F>
+bool eachArray(FlatScene& fl, F&& io) {
+  return io(fl.tlas) && io(fl.instances) && io(fl.geometries) && io(fl.blasNodes) && io(fl.triangles) && io(fl.faceNormals) &&
+         io(fl.vtxNormals) && io(fl.vtxUvs) && io(fl.materials) && io(fl.textures) && io(fl.texels) && io(fl.environment);
+}
+
+struct CacheHeader {
+  char magic[8];
+  uint64_t key;
+  ptx_camera camera;
+  pth_info info;
+  uint32_t envWidth, envHeight;
+};
+
+bool loadCache(const std::string& path, uint64_t key, pth_scene* s) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  struct stat st {};
+  if (fstat(fileno(f), &st) != 0) {
+    fclose(f);
+    return false;
+  }
+  CacheHeader h{};
+  bool ok = fread(&h, sizeof(h), 1, f) == 1 && memcmp(h.magic, kCacheMagic, 8) == 0 && h.key == key;
+  const uint64_t limit = (uint64_t)st.st_size;
+  ok = ok && eachArray(s->flat, [&](auto& v) { return getVec(f, v, limit); });
+  uint64_t tail = 0;
+  ok = ok && fread(&tail, sizeof(tail), 1, f) == 1 && tail == (key ^ 0x5043414348454f4bull);  // written last: a torn file has no tail
+  fclose(f);
+  if (!ok) return false;
+  s->flat.envWidth = h.envWidth;
+  s->flat.envHeight = h.envHeight;
+  s->flat.bind();
+  s->fromCache = true;
+  s->cachedCamera = h.camera;
+  s->cachedInfo = h.info;
+  return true;
+}
+
+bool storeCache(const std::string& path, uint64_t key, pth_scene* s) {
+  const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return false;
+  CacheHeader h{};
+  memcpy(h.magic, kCacheMagic, 8);
+  h.key = key;
+  pth_scene_camera(s, &h.camera);
+  pth_scene_info(s, &h.info);
+  h.envWidth = s->flat.envWidth;
+  h.envHeight = s->flat.envHeight;
+  bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+  ok = ok && eachArray(s->flat, [&](auto& v) { return putVec(f, v); });
+  const uint64_t tail = key ^ 0x5043414348454f4bull;
+  ok = ok && fwrite(&tail, sizeof(tail), 1, f) == 1;
+  ok = (fclose(f) == 0) && ok;
+  if (ok) ok = rename(tmp.c_str(), path.c_str()) == 0;  // readers see the old file or the complete new one
+  if (!ok) unlink(tmp.c_str());
+  return ok;
+}
+}  // namespace
+
+extern "C" {
+
+int pth_scene_create_cached(int preset, const char* models_dir, const char* env_path, uint32_t scatter_instances,
+                            uint32_t sky_w, uint32_t sky_h, const char* cache_dir, int* cache_hit, pth_scene** out) {
+  if (cache_hit) *cache_hit = 0;
+  if (!cache_dir || !*cache_dir) return pth_scene_create(preset, models_dir, env_path, scatter_instances, sky_w, sky_h, out);
+  if (!out || preset < 0 || preset > 2) {
+    g_err = "pth_scene_create_cached: bad arguments";
+    return -1;
+  }
+  SceneAssets defaults;
+  const std::string models = (models_dir && *models_dir) ? models_dir : defaults.modelsDir;
+  const std::string env = env_path ? env_path : "";
+  uint64_t key = 14695981039346656037ull;
+  key = fnv(key, kCacheMagic, 8);
+  const uint32_t params[5] = {(uint32_t)preset, scatter_instances, sky_w, sky_h, (uint32_t)sizeof(ptx_instance)};
+  key = fnv(key, params, sizeof(params));
+  if (preset == 2) {
+    key = fnvFile(key, models + "/viking-room/viking_room.obj", "absent");
+    key = fnvFile(key, models + "/viking-room/albedo.png", "absent");
+    key = fnvFile(key, models + "/viking-room/emissive.png", "absent");
+  } else {
+    key = fnvFile(key, models + "/bust-of-menelaus.stl", "stand-in bust v1");
+  }
+  key = fnvFile(key, env, "stand-in sky v1");
+  mkdir(cache_dir, 0777);
+  char name[64];
+  snprintf(name, sizeof(name), "/scene%d_%016llx.ptxflat", preset, (unsigned long long)key);
+  const std::string path = std::string(cache_dir) + name;
+  auto* s = new pth_scene();
+  if (loadCache(path, key, s)) {
+    if (cache_hit) *cache_hit = 1;
+    *out = s;
+    return 0;
+  }
+  delete s;
+  int rc = pth_scene_create(preset, models_dir, env_path, scatter_instances, sky_w, sky_h, out);
+  if (rc == 0) (void)storeCache(path, key, *out);  // a cache that cannot be written is not an error
+  return rc;
+}
 
 uint32_t pth_heatmap_colour(const uint32_t* counts, uint32_t n, float* rgb) {
   return heatmapColour(counts, n, rgb);

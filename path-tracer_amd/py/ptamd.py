@@ -122,6 +122,9 @@ def host_lib():
         lib.pth_scene_create.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.POINTER(C.c_void_p)]
         lib.pth_scene_create.restype = C.c_int
+        lib.pth_scene_create_cached.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p,
+                                                C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        lib.pth_scene_create_cached.restype = C.c_int
         lib.pth_scene_desc.argtypes = [C.c_void_p]
         lib.pth_scene_desc.restype = C.POINTER(SceneDesc)
         lib.pth_scene_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
@@ -153,11 +156,19 @@ def host_lib():
 class HostScene:
     """A preset scene built by the host pipeline (getScene + completeScene + flatten)."""
 
-    def __init__(self, preset, scatter_instances=0, sky=(0, 0), models_dir=None, env_path=None):
+    def __init__(self, preset, scatter_instances=0, sky=(0, 0), models_dir=None, env_path=None, cache_dir=None):
         lib = host_lib()
         self._h = C.c_void_p()
-        rc = lib.pth_scene_create(preset, (models_dir or MODELS_DIR).encode(), (env_path or ENV_PATH).encode(),
-                                  scatter_instances, sky[0], sky[1], C.byref(self._h))
+        self.cache_hit = False
+        if cache_dir:  # flattened-scene cache (pt_host.h: pth_scene_create_cached)
+            hit = C.c_int(0)
+            rc = lib.pth_scene_create_cached(preset, (models_dir or MODELS_DIR).encode(), (env_path or ENV_PATH).encode(),
+                                             scatter_instances, sky[0], sky[1], str(cache_dir).encode(), C.byref(hit),
+                                             C.byref(self._h))
+            self.cache_hit = bool(hit.value)
+        else:
+            rc = lib.pth_scene_create(preset, (models_dir or MODELS_DIR).encode(), (env_path or ENV_PATH).encode(),
+                                      scatter_instances, sky[0], sky[1], C.byref(self._h))
         if rc != 0:
             raise RuntimeError(lib.pth_last_error().decode())
         self.preset = preset

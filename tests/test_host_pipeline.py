@@ -167,3 +167,43 @@ def test_parallel_builder_makes_the_identical_tree(monkeypatch):
         assert np.array_equal(built["1"][1], built[threads][1])
         assert np.array_equal(built["1"][2], built[threads][2])
     assert built["1"][0].shape[0] > 500000
+
+
+def test_flattened_scene_cache(tmp_path):
+    """SURVEY.md 8f-4: pth_scene_create_cached keys the flattened arrays by the content of the assets;
+    a hit hands back byte-identical arrays, camera and info; a damaged file is ignored and rewritten."""
+    import glob
+    import os
+    import numpy as np
+
+    def arrays(s):
+        return [s.tlas_nodes.copy(), s.blas_nodes.copy(), s.triangles.copy(), s.instances.copy(),
+                np.ctypeslib.as_array(s.desc.environment, shape=(s.desc.env_width * s.desc.env_height * 3,)).copy(),
+                np.ctypeslib.as_array(s.desc.texels, shape=(s.desc.texel_total * 3,)).copy(),
+                np.ctypeslib.as_array(s.desc.face_normals, shape=(s.desc.face_normal_total * 3,)).copy()]
+
+    plain = ptamd.HostScene(2, sky=(64, 32))
+    first = ptamd.HostScene(2, sky=(64, 32), cache_dir=tmp_path)
+    assert not first.cache_hit
+    files = glob.glob(str(tmp_path / "scene2_*.ptxflat"))
+    assert len(files) == 1
+    second = ptamd.HostScene(2, sky=(64, 32), cache_dir=tmp_path)
+    assert second.cache_hit
+    for a, b, c in zip(arrays(plain), arrays(first), arrays(second)):
+        assert a.tobytes() == b.tobytes() == c.tobytes()
+    assert bytes(plain.camera) == bytes(second.camera)
+    for f in ("triangles_per_mesh", "blas_nodes", "tlas_nodes", "instances", "blas_depth", "stand_in_environment"):
+        assert getattr(plain.info, f) == getattr(second.info, f)
+    assert second.info.blas_nodes == 4899          # the README pin survives the round trip
+    # other parameters -> other key
+    other = ptamd.HostScene(2, sky=(32, 16), cache_dir=tmp_path)
+    assert not other.cache_hit and len(glob.glob(str(tmp_path / "*.ptxflat"))) == 2
+    # a truncated file is not trusted
+    size = os.path.getsize(files[0])
+    with open(files[0], "r+b") as f:
+        f.truncate(size // 2)
+    again = ptamd.HostScene(2, sky=(64, 32), cache_dir=tmp_path)
+    assert not again.cache_hit
+    assert os.path.getsize(files[0]) == size
+    for s in (plain, first, second, other, again):
+        s.close()
