@@ -50,7 +50,7 @@ constexpr uint32_t kLdsStack = PTX_LDS_STACK;  // stack entries per lane kept in
 #define PTX_SHADE_THRESHOLD 16  // waiting lanes that trigger the shading phase
 #endif
 #ifndef PTX_ENTER_THRESHOLD
-#define PTX_ENTER_THRESHOLD 1   // lanes at a TLAS leaf before the (rare, long) instance-entry body is run
+#define PTX_ENTER_THRESHOLD 4   // lanes at a TLAS leaf before the (rare, long) instance-entry body is run
 #endif
 #ifndef PTX_RARE_PERIOD
 #define PTX_RARE_PERIOD 1      // run the instance entry / exit bodies on every n-th iteration only
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       bool isExit = ref == kRefInstExit;
       const bool isTri = (ref >> 30) == 2u;
       bool isEnter = (ref >> 30) == 3u && !isSpecial;
-      if (PTX_ENTER_THRESHOLD > 1) {
+      if (PTX_ENTER_THRESHOLD > 1 && MODE == kModeRadiance) {
         // the instance-entry body is long and rarely needed: run it when a few lanes want it, or when
         // nothing else is left to do in this wave
         const uint32_t nEnter = (uint32_t)__popcll(__ballot(isEnter));
