@@ -1,33 +1,37 @@
 // Kernels of the gfx950 backend.
 //
 // pathKernel is a persistent, wavefront-style state machine: the grid is sized to the chip (not to
-// the image), every lane owns one pixel at a time and pulls the next one from a global work counter
-// when its pixel is finished, and inside the main loop each lane advances its own ray by one step
-// per iteration.  The lane's whole traversal state is the one-dword node reference it holds
-// (device_scene.hpp):
+// the image), every lane owns one work item at a time -- a pixel, or one RNG stream of a pixel
+// (ptx_params.sub_streams) -- and pulls the next one from a global work counter when it is finished,
+// and inside the main loop each lane advances its own ray by one step per iteration.  The lane's
+// whole traversal state is the one-dword node reference it holds (device_scene.hpp):
 //
-//      internal node  : two slab tests on one 64-byte NodePair, order, push far child
+//      internal node  : `-a` heat map: two slab tests on one 64-byte NodePair, order, push far child
+//                       radiance    : up to four quantised child boxes of one 64-byte WideNode
+//                                     (wide_bvh.hpp), sort, push up to three
 //      BLAS leaf      : one Moeller-Trumbore test
 //      TLAS leaf      : enter the next instance (ray -> object space, marker pushed)
 //      kRefInstExit   : leave the instance (ray -> world space)
 //      kRefDone       : traversal finished, wait for the shading phase
-//      kRefIdle       : no pixels left
+//      kRefIdle       : no work left
 //
-// Every iteration all lanes issue the same memory operations first -- an LDS read of their stack
-// top and ONE 64-byte fetch of the record their state needs (NodePair, TriRec or InstXform live in
-// one arena and are addressed from its base) -- so an iteration pays one memory latency, not one
-// per state; the state bodies then run from registers, predicated, and the iteration ends with one
-// LDS write of the slot above the stack top.  TLAS and BLAS nodes are the same records, so lanes
-// walking the TLAS and lanes inside an instance share the node-step code.  Lanes whose ray has
+// Every iteration a lane reads its stack top from LDS and fetches the one record its state needs
+// (NodePair / WideNode, TriRec or InstXform: all live in one arena and are addressed from its base)
+// -- only the 16-byte quarters its step uses, because the vector memory path charges per load
+// instruction and active lane -- so an iteration pays one memory latency, not
+// one per state; the state bodies then run from registers, predicated, and the iteration ends with
+// the LDS write(s) of the slots above the stack top.  TLAS and BLAS nodes are the same records, so
+// lanes walking the TLAS and lanes inside an instance share the node-step code.  Lanes whose ray has
 // finished wait until a quarter of the wave (or PTX_SHADE_THRESHOLD lanes) is waiting; then the
 // shading phase runs once for all of them: shade the hit / look up the environment, accumulate,
-// write finished pixels, pull new pixels, generate the next ray.  Because every lane always has a
-// ray in flight, a wave is never held hostage by its slowest path, and an image with 100x cost
-// differences between pixels (scene 1) load-balances through the counter.
+// write finished items, pull new ones, generate the next ray.  Because every lane always has a ray in
+// flight, a wave is never held hostage by its slowest path, and an image with 100x cost differences
+// between pixels (scene 1) load-balances through the counter.
 //
-// Per-ray visit order, ray.t at every slab test and every rounding are those of the reference's
-// nested traversal (intersection.hpp:99-233), so the `-a` counts are bit-exact against the CPU
-// path and the radiance path draws the same random numbers as the reference's GPU kernel.
+// `-a`: per-ray visit order, ray.t at every slab test and every rounding are those of the reference's
+// nested traversal (intersection.hpp:99-233), so the counts are bit-exact against the CPU path.
+// Radiance draws the same random numbers as the reference's GPU kernel and finds the same hits through
+// the wide layout (same leaves, same triangle arithmetic; see wide_bvh.hpp for what may differ).
 #pragma once
 
 #include "../host/colors.hpp"
