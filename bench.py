@@ -51,11 +51,13 @@ def algorithmic_bytes(st, width, height, hit_bytes=12):
             + 12 * width * height)
 
 
-def cpu_baseline(scene, budget_s=15.0, threads=None):
+def cpu_baseline(scene, budget_s=None, threads=None):
     """Times the oracle on the host cores: same scene/BVH/resolution/bounces, reduced spp."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_binding as ob
     import ptamd
+    if budget_s is None:
+        budget_s = float(os.environ.get("PTX_BENCH_CPU_BUDGET", "15"))  # seconds of CPU work (tests shorten it)
     threads = threads or min(os.cpu_count() or 1, 16)  # the GPU box's CPU share for one GPU is 16
     p = ptamd.make_params(WIDTH, HEIGHT, spp=2, max_bounces=BOUNCES)
     _, st = ob.render(scene, p, seed_mode=ptamd.SEED_REFERENCE_GPU, threads=threads)

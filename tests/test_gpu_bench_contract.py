@@ -1,0 +1,33 @@
+"""bench.py end to end on the GPU at a reduced sample count: one JSON line with the fields the driver reads."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    env = dict(os.environ, PTX_BENCH_CPU_BUDGET="1")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "1", "--spp", "4"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["metric"] == "Mrays/s at 1500x800, 100spp, 6 bounces, Scene 1" and j["unit"] == "Mrays/s"
+    assert j["n_gpus"] == 1 and j["steps"] == 1 and j["warmup"] == 1 and j["higher_is_better"] is True
+    assert j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "f32" and j["data"] == "synthetic"
+    assert j["value"] > 0 and j["ms_per_step"] > 0
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert "traffic" in r and r["memory_path"]["frac"] > 0
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    # value = rays of the timed steps / wall time
+    assert abs(j["value"] - j["config"]["rays_per_step"] / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * j["value"]
