@@ -213,6 +213,8 @@ int persistentGrid(ptx_scene* s, K kernel, uint32_t& blocks) {
   int perCu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, (int)kBlockThreads, 0));
   if (perCu < 1) perCu = 1;
+  static const char* cap = getenv("PTX_MAX_BLOCKS_PER_CU");  // experiments only
+  if (cap && atoi(cap) >= 1 && atoi(cap) < perCu) perCu = atoi(cap);
   blocks = (uint32_t)(s->numCus * perCu);
   return PTX_OK;
 }
