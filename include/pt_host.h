@@ -37,6 +37,12 @@ typedef struct pth_info {
 int pth_scene_create(int preset, const char* models_dir, const char* env_path,
                      uint32_t scatter_instances, uint32_t sky_width, uint32_t sky_height,
                      pth_scene** out);
+/* Writes the stand-in bust (the geometry used when models/bust-of-menelaus.stl is absent) as a binary STL
+ * file, with one degenerate facet (a vertex named twice) inserted after every `degenerate_every` facets
+ * (0 = none), so that the STL ingest path -- input.cpp:12-33 incl. stl_reader's removal of such facets --
+ * can be exercised and timed on a file of the scan's size.  Returns the number of facets written or -1. */
+long pth_write_standin_stl(const char* path, uint32_t degenerate_every);
+
 /* The same, through an on-disk cache of the FLATTENED scene: the key is a hash of the
  * preset, its parameters and the CONTENT of every asset file the preset reads (or the stand-in
  * generator's version when a file is absent); a hit skips asset parsing, the BVH builds and the

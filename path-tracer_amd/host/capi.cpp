@@ -240,6 +240,28 @@ int pth_write_bmp(const char* path, const float* rgb, uint32_t w, uint32_t h) {
   return writeBmp(path, rgb, w, h) ? 0 : -1;
 }
 
+long pth_write_standin_stl(const char* path, uint32_t degenerate_every) {
+  if (!path) return -1;
+  const bool quiet = g_quiet;
+  g_quiet = true;
+  std::vector<Triangle> tris = standInBust();
+  g_quiet = quiet;
+  if (degenerate_every) {
+    std::vector<Triangle> with;
+    with.reserve(tris.size() + tris.size() / degenerate_every + 1);
+    for (size_t i = 0; i < tris.size(); i++) {
+      with.push_back(tris[i]);
+      if ((i + 1) % degenerate_every == 0) {
+        Triangle d = tris[i];
+        d.v2 = d.v0;  // names one vertex twice: stl_reader drops it
+        with.push_back(d);
+      }
+    }
+    tris.swap(with);
+  }
+  return writeBinarySTL(path, tris) ? (long)tris.size() : -1;
+}
+
 uint32_t pth_bmp_row_bytes(uint32_t w) { return bmpRowBytes(w); }
 void pth_quantise_rows(const float* rgb, uint32_t w, uint32_t h, unsigned char* rows) { quantiseRows(rgb, w, h, rows); }
 int pth_write_bmp_rows(const char* path, const unsigned char* rows, uint32_t w, uint32_t h) {

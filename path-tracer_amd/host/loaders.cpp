@@ -1,5 +1,9 @@
 #include "loaders.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -213,28 +217,60 @@ std::vector<Triangle> loadObj(const std::string& path, std::vector<vec3>& normal
 // STL
 // ---------------------------------------------------------------------------------------------
 
-std::vector<Triangle> loadSTL(const std::string& path) {
-  std::vector<unsigned char> buf;
-  std::vector<Triangle> tris;
-  if (!readFile(path, buf)) return tris;
-  bool binary = false;
-  if (buf.size() >= 84) {
-    uint32_t n;
-    memcpy(&n, buf.data() + 80, 4);
-    binary = (buf.size() == 84 + (size_t)n * 50);
+bool writeBinarySTL(const std::string& path, const std::vector<Triangle>& tris) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return false;
+  std::vector<unsigned char> buf(84 + tris.size() * 50, 0);
+  const char* tag = "binary STL written by path-tracer_amd (stand-in geometry)";
+  memcpy(buf.data(), tag, strlen(tag));
+  const uint32_t n = (uint32_t)tris.size();
+  memcpy(buf.data() + 80, &n, 4);
+  for (uint32_t i = 0; i < n; i++) {
+    const float v[9] = {tris[i].v0.x, tris[i].v0.y, tris[i].v0.z, tris[i].v1.x, tris[i].v1.y, tris[i].v1.z,
+                        tris[i].v2.x, tris[i].v2.y, tris[i].v2.z};
+    memcpy(buf.data() + 84 + (size_t)i * 50 + 12, v, 36);
   }
-  if (binary) {
-    uint32_t n;
-    memcpy(&n, buf.data() + 80, 4);
-    tris.resize(n);
-    for (uint32_t i = 0; i < n; i++) {
-      float f[12];
-      memcpy(f, buf.data() + 84 + (size_t)i * 50, 48);
-      tris[i].v0 = vec3{f[3], f[4], f[5]};
-      tris[i].v1 = vec3{f[6], f[7], f[8]};
-      tris[i].v2 = vec3{f[9], f[10], f[11]};
+  const bool ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+  return (fclose(f) == 0) && ok;
+}
+
+std::vector<Triangle> loadSTL(const std::string& path) {
+  std::vector<Triangle> tris;
+  // binary files: map, check the size against the facet count, convert in place of a copy + parse
+  {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return tris;
+    struct stat st {};
+    if (fstat(fd, &st) != 0 || st.st_size < 84) {
+      close(fd);
+    } else {
+      void* map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      close(fd);
+      if (map != MAP_FAILED) {
+        const unsigned char* base = (const unsigned char*)map;
+        uint32_t n;
+        memcpy(&n, base + 80, 4);
+        const bool binary = (size_t)st.st_size == 84 + (size_t)n * 50;
+        if (binary) {
+          tris.reserve(n);
+          for (uint32_t i = 0; i < n; i++) {
+            float f[9];
+            memcpy(f, base + 84 + (size_t)i * 50 + 12, 36);
+            Triangle t;
+            t.v0 = vec3{f[0], f[1], f[2]};
+            t.v1 = vec3{f[3], f[4], f[5]};
+            t.v2 = vec3{f[6], f[7], f[8]};
+            tris.push_back(t);
+          }
+        }
+        munmap(map, (size_t)st.st_size);
+        if (binary) goto loaded;
+      }
     }
-  } else {
+  }
+  {
+    std::vector<unsigned char> buf;
+    if (!readFile(path, buf)) return tris;
     std::string text((const char*)buf.data(), buf.size());
     size_t pos = 0;
     std::vector<vec3> vs;
@@ -253,6 +289,7 @@ std::vector<Triangle> loadSTL(const std::string& path) {
       tris.push_back(t);
     }
   }
+loaded:
   // stl_reader merges vertices with exactly equal coordinates and then drops every triangle that
   // references one vertex twice (stl_reader.h:498-521); order is otherwise preserved.
   auto same = [](vec3 a, vec3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; };

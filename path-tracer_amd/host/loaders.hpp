@@ -24,7 +24,13 @@ bool fileExists(const std::string& path);
 
 Image loadImage(const std::string& path);             // input.cpp:132-147; width 0 on failure
 Image loadEnvironmentImage(const std::string& path);  // input.cpp:117-130; width 0 on failure
-std::vector<Triangle> loadSTL(const std::string& path);  // input.cpp:12-33; empty on failure
+// input.cpp:12-33; empty on failure.  Binary files are memory-mapped and converted in one pass;
+// stl_reader's sort-based vertex merge (stl_reader.h:464) is not repeated: the only thing the reference
+// keeps from it is "a triangle that names one vertex twice is dropped", which is decided per triangle.
+std::vector<Triangle> loadSTL(const std::string& path);
+// Writes a binary STL (80-byte header, count, 50 bytes per facet with a zero normal): the synthetic
+// stand-in of the absent scan as a FILE, so that the ingest path can be exercised and timed.
+bool writeBinarySTL(const std::string& path, const std::vector<Triangle>& tris);
 std::vector<Triangle> loadObj(const std::string& path, std::vector<vec3>& normals,
                               std::vector<vec2>& texCoords);  // input.cpp:35-114
 

@@ -125,6 +125,8 @@ def host_lib():
         lib.pth_scene_create_cached.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p,
                                                 C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
         lib.pth_scene_create_cached.restype = C.c_int
+        lib.pth_write_standin_stl.argtypes = [C.c_char_p, C.c_uint32]
+        lib.pth_write_standin_stl.restype = C.c_long
         lib.pth_scene_desc.argtypes = [C.c_void_p]
         lib.pth_scene_desc.restype = C.POINTER(SceneDesc)
         lib.pth_scene_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]

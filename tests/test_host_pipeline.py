@@ -207,3 +207,28 @@ def test_flattened_scene_cache(tmp_path):
     assert os.path.getsize(files[0]) == size
     for s in (plain, first, second, other, again):
         s.close()
+
+
+def test_stl_ingest_of_a_scan_sized_file(tmp_path):
+    """the Menelaus scan is absent, so the stand-in bust is written as a binary STL of the
+    scan's size, with facets that name a vertex twice mixed in; the memory-mapped loader has to drop
+    exactly those (stl_reader.h:498-521) and hand the scene pipeline the same triangles as the generator."""
+    import shutil
+    import time
+    models = tmp_path / "models"
+    models.mkdir()
+    n = ptamd.host_lib().pth_write_standin_stl(str(models / "bust-of-menelaus.stl").encode(), 1000)
+    assert n == 505848 + 505
+    assert (models / "bust-of-menelaus.stl").stat().st_size == 84 + 50 * n
+    t0 = time.time()
+    from_file = ptamd.HostScene(0, models_dir=str(models), sky=(64, 32))
+    dt = time.time() - t0
+    generated = ptamd.HostScene(0, sky=(64, 32))
+    assert from_file.info.stand_in_geometry == 0 and generated.info.stand_in_geometry == 1
+    assert from_file.info.triangles_per_mesh == 505848
+    assert from_file.triangles.tobytes() == generated.triangles.tobytes()
+    assert from_file.blas_nodes.tobytes() == generated.blas_nodes.tobytes()
+    assert dt < 60
+    from_file.close()
+    generated.close()
+    shutil.rmtree(models)
