@@ -71,3 +71,33 @@ def test_wide_and_binary_layouts_count_the_same_rays(gpu_scenes):
     assert abs(int(st.rays) - int(st_ref.rays)) <= max(8, int(0.02 * st_ref.rays))
     assert st.node_steps < 0.7 * st_ref.node_steps
     assert abs(int(st.tri_tests) - int(st_ref.tri_tests)) <= 0.1 * st_ref.tri_tests
+
+
+@pytest.mark.gpu
+def test_wide_and_binary_layouts_render_the_same_image(gpu_scenes, tmp_path):
+    """Same seeds, same triangles, same Moeller-Trumbore arithmetic: the two layouts may only differ where a
+    tie in t or a one-rounding box miss resolves differently, i.e. in (almost) no pixel."""
+    import os
+    import subprocess
+    import sys
+    hosts, devs = gpu_scenes
+    out = str(tmp_path / "binary.npy")
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.dirname(ptamd.__file__)!r})\n"
+        "import ptamd\n"
+        "for preset in (2, 1):\n"
+        "    s = ptamd.HostScene(preset); d = ptamd.DeviceScene(s.desc_ptr)\n"
+        "    img, _ = d.render(s.camera, ptamd.make_params(160, 96, spp=8, max_bounces=6))\n"
+        f"    np.save({out!r} + str(preset) + '.npy', img)\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PTX_WIDE="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for preset, min_same in ((2, 0.999), (1, 0.995)):
+        binary = np.load(out + str(preset) + ".npy")
+        wide, _ = devs[preset].render(hosts[preset].camera, ptamd.make_params(160, 96, spp=8, max_bounces=6))
+        same = (np.abs(wide - binary).max(axis=2) == 0).mean()
+        rms = float(np.sqrt(np.mean((wide.astype(np.float64) - binary) ** 2)))
+        print(f"scene {preset}: {same * 100:.3f} % of pixels bit-identical, RMSE {rms:.2e}")
+        assert same >= min_same
+        assert rms < 5e-3
