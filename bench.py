@@ -4,10 +4,12 @@
     python bench.py --gpus N --steps K --warmup W
 
 One process per GPU (the driver launches N>1 through torch.distributed.run; RCCL = backend "nccl").
-A step is one full pass of the hot path: every rank path-traces the whole 1500x800 frame at 100 spp
-with its own RNG streams (sample-slice partition, weak scaling: the job is an N*100-spp frame), the
-un-normalised float accumulation buffers are summed onto rank 0 with one RCCL reduce, and rank 0
+A step is one full pass of the hot path over BASELINE's frame: the 100 samples of every pixel are split
+over the ranks (sample-slice partition, STRONG scaling: the job is the same 1500x800 x 100-spp frame
+at every N; rank r traces split_samples(100, N)[r] samples of every pixel with its own RNG streams),
+the un-normalised float accumulation buffers are summed onto rank 0 with one RCCL reduce, and rank 0
 divides, colour-grades and tonemaps.  The scene is resident in HBM before the timed region.
+(--weak keeps 100 spp per GPU: an N*100-spp frame.)
 
 RNG streams: the reference seeds one serial stream per pixel (gpuRender.cu:130), i.e. 1.2 M
 independent chains of 100 samples for this frame -- fewer than four per lane of an MI355X, so the
@@ -81,6 +83,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-seeding", action="store_true", help="skip the extra frame with the reference's seeding")
     ap.add_argument("--sub-streams", type=int, default=25, help="RNG streams per pixel and GPU (1 = the reference's seeding)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: 100 spp on every GPU (the job grows with N)")
     ap.add_argument("--spp", type=int, default=SPP, help=argparse.SUPPRESS)  # profiling runs only
     # rehearsal of the N > 1 path on a box with one GPU: every rank on cuda:0, buffers reduced through gloo
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help=argparse.SUPPRESS)
@@ -125,14 +128,17 @@ def main():
         else:
             dist.all_reduce(t, op=op)
 
-    spp = args.spp
+    import multigpu
+    frame_spp = args.spp * world if args.weak else args.spp            # samples per pixel of the whole job
+    spp = multigpu.split_samples(frame_spp, world)[rank]               # this rank's share
+    sub_streams = max(1, min(args.sub_streams, spp))
     # replicated on every GPU; the flattened arrays come from the on-disk cache when an earlier run (or
     # another rank) on this machine has built them (pt_host.h: pth_scene_create_cached)
     import tempfile
     scene = ptamd.HostScene(SCENE, cache_dir=os.path.join(tempfile.gettempdir(), "ptx_scene_cache"))
     dscene = ptamd.DeviceScene(scene.desc_ptr, device=local_rank)
     params = ptamd.make_params(WIDTH, HEIGHT, spp=spp, max_bounces=BOUNCES, seed_mode=ptamd.SEED_STREAM,
-                               part_index=rank, part_count=world, sub_streams=args.sub_streams)
+                               part_index=rank, part_count=world, sub_streams=sub_streams, frame_spp=frame_spp)
     accum = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev)
     out = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=dev)
     out1 = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=dev)
@@ -146,7 +152,7 @@ def main():
             dscene.resolve_device(accum.data_ptr(), WIDTH, HEIGHT, out.data_ptr(), stream)
 
     # exact ray / node / triangle counts of this rank's launch (instrumented kernel, untimed)
-    stats = dscene.measure(scene.camera, params)
+    stats = dscene.measure(scene.camera, params) if spp > 0 else ptamd.Stats()
 
     for _ in range(args.warmup):
         step()
@@ -157,7 +163,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_s.append(dscene.last_kernel_seconds())  # HIP events on the launch stream
+        if spp > 0:
+            kernel_s.append(dscene.last_kernel_seconds())  # HIP events on the launch stream
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -173,18 +180,29 @@ def main():
 
     ref_seed = None
     if rank == 0 and world == 1 and args.sub_streams > 1 and not args.no_reference_seeding:
-        # the same frame with the reference's seeding (one stream per pixel), one step, for the record
+        # the same frame with the reference's seeding (one stream per pixel, the random sequence of
+        # gpuRender.cu:130), timed with the same protocol: warm-up, K steps between synchronisations, kernel
+        # time from HIP events
         p1 = ptamd.make_params(WIDTH, HEIGHT, spp=spp, max_bounces=BOUNCES, seed_mode=ptamd.SEED_REFERENCE_GPU)
         st1 = dscene.measure(scene.camera, p1)
         stream = torch.cuda.current_stream().cuda_stream
+
+        def step1():
+            dscene.accumulate_device(scene.camera, p1, accum.data_ptr(), stream)
+            dscene.resolve_device(accum.data_ptr(), WIDTH, HEIGHT, out1.data_ptr(), stream)
+
+        for _ in range(args.warmup):
+            step1()
         torch.cuda.synchronize()
+        k1 = []
         t1 = time.perf_counter()
-        dscene.accumulate_device(scene.camera, p1, accum.data_ptr(), stream)
-        dscene.resolve_device(accum.data_ptr(), WIDTH, HEIGHT, out1.data_ptr(), stream)
+        for _ in range(args.steps):
+            step1()
+            k1.append(dscene.last_kernel_seconds())
         torch.cuda.synchronize()
-        dt1 = time.perf_counter() - t1
-        ref_seed = {"value": st1.rays / dt1 / 1e6, "unit": "Mrays/s", "ms_per_step": dt1 * 1e3, "rays_per_step": st1.rays,
-                    "steps": 1}
+        dt1 = (time.perf_counter() - t1) / args.steps
+        ref_seed = {"value": st1.rays / dt1 / 1e6, "unit": "Mrays/s", "ms_per_step": dt1 * 1e3, "kernel_ms": sum(k1) / len(k1) * 1e3,
+                    "rays_per_step": st1.rays, "steps": args.steps, "warmup": args.warmup}
 
     if rank == 0:
         img = out.cpu().numpy()
@@ -206,20 +224,20 @@ def main():
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"scene 1 (SCATTER_STL: 10,000 instances of one {scene.info.triangles_per_mesh}-triangle "
-                            f"BLAS, {scene.info.tlas_nodes}-node TLAS) {WIDTH}x{HEIGHT}, {spp} spp per GPU, "
-                            f"{BOUNCES} bounces",
+                            f"BLAS, {scene.info.tlas_nodes}-node TLAS) {WIDTH}x{HEIGHT}, {frame_spp} spp per frame"
+                            f" ({'+'.join(str(n) for n in multigpu.split_samples(frame_spp, world))} per GPU), {BOUNCES} bounces",
                 "geometry": "procedural stand-in bust (models/bust-of-menelaus.stl absent)"
                             if scene.info.stand_in_geometry else "bust-of-menelaus.stl",
                 "environment": "analytic stand-in sky (HDR absent)" if scene.info.stand_in_environment else "HDR",
-                "partition": "whole frame per GPU, own RNG streams per GPU, RCCL sum-reduce of W*H*4 f32 to rank 0"
-                             if world > 1 else "single GPU",
-                "rng_streams_per_pixel_per_gpu": args.sub_streams,
+                "partition": "sample slices: every GPU traces its share of each pixel's samples with its own RNG streams, "
+                             "RCCL sum-reduce of W*H*4 f32 to rank 0" if world > 1 else "single GPU",
+                "rng_streams_per_pixel_per_gpu": sub_streams,
                 "reference_seeding": ref_seed,
-                "rays_per_step": total_rays, "paths_per_step": WIDTH * HEIGHT * spp * world,
+                "rays_per_step": total_rays, "paths_per_step": WIDTH * HEIGHT * frame_spp,
             },
             "roofline": {
                 "bound": "hbm", "achieved": alg / avg_kernel / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -141,6 +141,12 @@ typedef struct ptx_params {
                               has one serial stream per pixel, i.e. W*H independent chains; a chip with
                               more lanes than that idles through the tail of every frame.  0 or 1 = one
                               stream (required for PTX_SEED_REFERENCE_GPU); at most 256. */
+  uint32_t frame_spp;    /* samples per pixel of the WHOLE frame when this call renders a share of it (sample-slice
+                              split: the sum of spp over all parts); 0 = this call is the whole frame (= spp).
+                              The reference jitters the camera ray iff the frame has more than one sample
+                              (gpuRender.cu:134 `samples > 1`): a share of one sample of an N-sample frame must still
+                              be jittered, and a share of zero samples (more parts than samples; allowed only with
+                              frame_spp > 0, radiance device entry points) yields an all-zero accumulation buffer. */
 } ptx_params;
 
 typedef struct ptx_stats {
@@ -202,7 +208,10 @@ int ptx_render_bgr8(ptx_scene* scene, const ptx_camera* camera, const ptx_params
  *                           gpuRender.cu:158-169 -- after the caller has summed the buffers of all
  *                           parts (RCCL reduce).
  *   ptx_counts_device     : heat-map counts for this part's tiles into d_counts (uint32 per pixel,
- *                           0 outside the part), so a sum-reduce reassembles the frame exactly. */
+ *                           0 outside the part), so a sum-reduce reassembles the frame exactly.
+ * A handle owns one set of per-launch scratch (work counter, stack overflow area, stream planes, timing
+ * events): at most ONE launch per handle may be in flight.  Launches through one handle on one stream
+ * are ordered and fine; for concurrent launches on several streams create one handle per stream. */
 int ptx_accumulate_device(ptx_scene* scene, const ptx_camera* camera, const ptx_params* params,
                           float* d_accum, void* hip_stream);
 int ptx_resolve_device(ptx_scene* scene, const float* d_accum, uint32_t width, uint32_t height,

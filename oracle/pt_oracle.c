@@ -501,6 +501,9 @@ static void* worker(void* arg) {
   const float resx = (float)W, resy = (float)Hh;
   const uint32_t samples = job->mode == 0 ? 1u : P->spp;
   const uint32_t parts = P->part_count > 1u ? P->part_count : 1u;
+  /* main.cpp:204 `samples > 1` speaks of the frame's sample count; a call that renders a share of a frame
+   * (sample-slice split) says so in frame_spp (include/ptx_backend.h) */
+  const int jitter = (P->frame_spp ? P->frame_spp : samples) > 1u;
 
   for (uint32_t idx = atomic_fetch_add_explicit(job->next, 1u, memory_order_relaxed); idx < N;
        idx = atomic_fetch_add_explicit(job->next, 1u, memory_order_relaxed)) {
@@ -532,7 +535,7 @@ static void* worker(void* arg) {
     v3 col = V3(0, 0, 0);
     for (uint32_t s = 0; s < samples; s++) {
       float sx = fx, sy = fy;
-      if (samples > 1u) { /* main.cpp:204-207 */
+      if (jitter) { /* main.cpp:204-207 */
         v2 xi = random_vec2(&rng);
         sx += 0.5f * (2.0f * xi.x - 1.0f);
         sy += 0.5f * (2.0f * xi.y - 1.0f);

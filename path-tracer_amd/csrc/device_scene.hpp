@@ -121,6 +121,7 @@ struct FrameConstants {
   float envQy, envQw;                     // quaternion (0, qy, 0, qw) of rotateY(dir, -M_PI)
   uint32_t width, height;
   uint32_t spp, maxBounces;
+  uint32_t jitter;      // the FRAME has more than one sample per pixel (gpuRender.cu:134)
   uint32_t seedBase;    // 1023u (+ stream offset)
   uint32_t partIndex, partCount;
   uint32_t tilesX, tilesY;

@@ -211,14 +211,17 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
           if (MODE == kModeCounts) {
             reinterpret_cast<uint32_t*>(outRaw)[pix] = count;
           } else if (hit.t < FLT_MAX) {
+            PTX_MARK("S_HIT");
             if (STATS) nHits++;
             shadeHit(sc, hit, wo, wd, rng, col);  // writes the next ray into wo / wd
             bounce++;
             pathEnded = bounce >= fc.maxBounces;  // gpuRender.cu:29: the loop ends, col is returned
           } else {
+            PTX_MARK("S_MISS");
             if (STATS) nMisses++;
             col *= environmentLookup(sc, fc, wd);
           }
+          PTX_MARK("S_AFTER");
           if (MODE == kModeRadiance && pathEnded) {
             sum += col;
             sample--;
@@ -226,6 +229,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
         }
         bool live = true;
         if (pathEnded) {
+          PTX_MARK("S_PULL");
           // ---- item finished? write it and pull the next one ----
           while (sample == 0u && live) {
             if (MODE == kModeRadiance && havePixel) {
@@ -263,11 +267,12 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
             }
           }
           if (live) {
+            PTX_MARK("S_CAMERA");
             // ---- next camera ray: gpuRender.cu:132-143 ----
             const uint32_t p = pix & 0x00FFFFFFu;
             const uint32_t py = p / fc.width, px = p - py * fc.width;
             float fx = (float)px, fy = (float)py;
-            if (MODE == kModeRadiance && fc.spp > 1u) {
+            if (MODE == kModeRadiance && fc.jitter) {
               const vec2 xi = pt::getRandomVec2(rng);
               fx += 0.5f * (2.0f * xi.x - 1.0f);
               fy += 0.5f * (2.0f * xi.y - 1.0f);
@@ -279,6 +284,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
           }
         }
         if (live) {
+          PTX_MARK("S_LAUNCH");
           // ---- launch the segment: Scene::intersect starts at the TLAS root ----
           reciprocalDir(wd, winv, wZeroDir);
           zeroDir = wZeroDir;

@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -102,6 +104,12 @@ int convertTree(const ptx_bvh_node* nodes, uint32_t n, uint32_t primBase, uint32
   return PTX_OK;
 }
 
+// Slots the binary-layout walk can touch: slot 0 holds the bottom marker, every internal level of the
+// TLAS and of the BLAS defers at most one child, the instance entry pushes its exit marker -- so sp
+// reaches tlasDepth + blasDepth + 2 -- and every stepping iteration writes slot sp (the write that is
+// not followed by sp++ leaves garbage above the top).  Slots 0 .. depth sum + 2: depth sum + 3 entries.
+inline uint32_t binaryStackBound(uint32_t tlasDepth, uint32_t blasDepth) { return tlasDepth + blasDepth + 3u; }
+
 template <typename T>
 size_t arenaReserve(size_t& cursor, size_t count) {
   cursor = (cursor + 255u) & ~size_t(255);
@@ -158,7 +166,8 @@ int makeFrame(const ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, 
   if (prm->width == 0 || prm->height == 0) return fail(PTX_EINVAL, "empty image");
   if ((uint64_t)prm->width * prm->height > (1ull << 24))
     return fail(PTX_ELIMIT, "more than 2^24 pixels: pixel coordinates would no longer be exact in float (main.cpp:199)");
-  if (!heatmap && prm->spp == 0) return fail(PTX_EINVAL, "spp must be > 0");
+  if (!heatmap && prm->spp == 0) return fail(PTX_EINVAL, "spp must be > 0 (a share of zero samples needs frame_spp > 0 and a device-buffer entry point)");
+  if (!heatmap && prm->frame_spp != 0 && prm->frame_spp < prm->spp) return fail(PTX_EINVAL, "frame_spp < spp");
   if (prm->part_count > 1u && prm->part_index >= prm->part_count) return fail(PTX_EINVAL, "part_index >= part_count");
   using pt::vec3;
   memset(&fc, 0, sizeof(fc));
@@ -188,6 +197,7 @@ int makeFrame(const ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, 
   fc.height = prm->height;
   fc.spp = heatmap ? 1u : prm->spp;
   fc.maxBounces = heatmap ? 1u : prm->max_bounces;
+  fc.jitter = (!heatmap && (prm->frame_spp ? prm->frame_spp : prm->spp) > 1u) ? 1u : 0u;
   uint32_t streams = (heatmap || prm->sub_streams == 0u) ? 1u : prm->sub_streams;
   if (streams > 1u && prm->seed_mode != PTX_SEED_STREAM)
     return fail(PTX_EINVAL, "sub_streams > 1 needs PTX_SEED_STREAM: the reference's seeding has one RNG stream per pixel");
@@ -208,39 +218,72 @@ int makeFrame(const ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, 
 }
 
 // Persistent launch: the grid is sized to the chip (CUs x resident blocks per CU), not to the image.
+// The occupancy query is made once per kernel and device (the no-allocation entry point may not make
+// runtime queries that could allocate).
 template <typename K>
 int persistentGrid(ptx_scene* s, K kernel, uint32_t& blocks) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> cache;
   int perCu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, (int)kBlockThreads, 0));
-  if (perCu < 1) perCu = 1;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(reinterpret_cast<const void*>(kernel), s->device);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, (int)kBlockThreads, 0));
+      if (perCu < 1) perCu = 1;
+      cache[key] = perCu;
+    } else {
+      perCu = it->second;
+    }
+  }
   static const char* cap = getenv("PTX_MAX_BLOCKS_PER_CU");  // experiments only
   if (cap && atoi(cap) >= 1 && atoi(cap) < perCu) perCu = atoi(cap);
   blocks = (uint32_t)(s->numCus * perCu);
   return PTX_OK;
 }
 
+// Device memory a launch needs beyond the scene, the inputs and the outputs.  Either the handle's own
+// buffers, grown on demand (ScratchOwner::handle), or slices of the library's static array (the
+// no-allocation entry point).
+struct Scratch {
+  uint32_t* workCounter = nullptr;  // one dword, cleared before every launch
+  uint32_t* overflow = nullptr;     // traversal-stack entries beyond the LDS part, [entry][thread]
+  float4* planes = nullptr;         // per-stream accumulation planes of a sub-stream launch
+};
+
+// What a radiance / counts launch will need: decided before any memory is touched, so that the two
+// scratch providers see the same numbers.
+struct LaunchPlan {
+  uint32_t blocks = 0;
+  bool wide = false;
+  size_t ovfBytes = 0;    // >= 4
+  size_t planeBytes = 0;  // 0: the kernel writes the caller's buffer itself
+};
+
 template <typename K>
-int launchPath(ptx_scene* s, K kernel, const FrameConstants& fc, void* dOut, hipStream_t stream, bool wide = false) {
+int planLaunch(ptx_scene* s, K kernel, const FrameConstants& fc, bool wide, LaunchPlan& plan) {
   uint32_t blocks = 0;
   int rc = persistentGrid(s, kernel, blocks);
   if (rc) return rc;
-  const uint32_t work = fc.width * fc.height;
+  // one lane per work item: pixels x RNG streams (checked in makeFrame to fit 32 bits)
+  const uint32_t work = fc.width * fc.height * fc.subStreams;
   const uint32_t needed = (work + kBlockThreads - 1u) / kBlockThreads;
   if (blocks > needed) blocks = needed;
-  // overflow area of the traversal stack: entries beyond the LDS part, [entry][thread]
-  const uint32_t bound = wide ? s->wideStackBound : s->tlasDepth + s->blasDepth + 2u;
+  const uint32_t bound = wide ? s->wideStackBound : binaryStackBound(s->tlasDepth, s->blasDepth);
   const size_t deepEntries = bound > kLdsStack ? bound - kLdsStack : 0u;
-  const size_t ovfBytes = (deepEntries ? deepEntries : 1u) * (size_t)blocks * kBlockThreads * sizeof(uint32_t);
-  if (s->ovfBytes < ovfBytes) {
-    if (s->dOverflow) HIP_TRY(hipFree(s->dOverflow));
-    s->dOverflow = nullptr;
-    s->ovfBytes = 0;
-    HIP_TRY(hipMalloc((void**)&s->dOverflow, ovfBytes));
-    s->ovfBytes = ovfBytes;
-  }
-  HIP_TRY(hipMemsetAsync(s->dWorkCounter, 0, sizeof(uint32_t), stream));
+  plan.blocks = blocks;
+  plan.wide = wide;
+  plan.ovfBytes = (deepEntries ? deepEntries : 1u) * (size_t)blocks * kBlockThreads * sizeof(uint32_t);
+  return PTX_OK;
+}
+
+template <typename K>
+int launchPath(ptx_scene* s, K kernel, const FrameConstants& fc, const LaunchPlan& plan, const Scratch& scr, void* dOut,
+               hipStream_t stream) {
+  HIP_TRY(hipMemsetAsync(scr.workCounter, 0, sizeof(uint32_t), stream));
   HIP_TRY(hipEventRecord(s->evStart, stream));
-  kernel<<<dim3(blocks), dim3(kBlockThreads), 0, stream>>>(s->dev, fc, s->dWorkCounter, dOut, s->dStats, s->dOverflow);
+  kernel<<<dim3(plan.blocks), dim3(kBlockThreads), 0, stream>>>(s->dev, fc, scr.workCounter, dOut, s->dStats, scr.overflow);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->evStop, stream));
   s->lastStream = stream;
@@ -248,9 +291,40 @@ int launchPath(ptx_scene* s, K kernel, const FrameConstants& fc, void* dOut, hip
   return PTX_OK;
 }
 
+// The handle's own scratch buffers, grown (never shrunk) to what the plan asks for.
+int handleScratch(ptx_scene* s, const LaunchPlan& plan, Scratch& scr) {
+  if (s->ovfBytes < plan.ovfBytes) {
+    if (s->dOverflow) HIP_TRY(hipFree(s->dOverflow));
+    s->dOverflow = nullptr;
+    s->ovfBytes = 0;
+    HIP_TRY(hipMalloc((void**)&s->dOverflow, plan.ovfBytes));
+    s->ovfBytes = plan.ovfBytes;
+  }
+  if (s->planeBytes < plan.planeBytes) {
+    if (s->dPlanes) HIP_TRY(hipFree(s->dPlanes));
+    s->dPlanes = nullptr;
+    s->planeBytes = 0;
+    HIP_TRY(hipMalloc((void**)&s->dPlanes, plan.planeBytes));
+    s->planeBytes = plan.planeBytes;
+  }
+  scr.workCounter = s->dWorkCounter;
+  scr.overflow = s->dOverflow;
+  scr.planes = s->dPlanes;
+  return PTX_OK;
+}
+
+enum class ScratchOwner { handle, library };
+
 int launchCounts(ptx_scene* s, const FrameConstants& fc, uint32_t* dOut, hipStream_t stream, bool stats) {
-  if (stats) return launchPath(s, pathKernel<kModeCounts, true, false>, fc, dOut, stream);
-  return launchPath(s, pathKernel<kModeCounts, false, false>, fc, dOut, stream);
+  auto go = [&](auto kernel) {
+    LaunchPlan plan;
+    Scratch scr;
+    int rc = planLaunch(s, kernel, fc, false, plan);
+    if (!rc) rc = handleScratch(s, plan, scr);
+    if (!rc) rc = launchPath(s, kernel, fc, plan, scr, dOut, stream);
+    return rc;
+  };
+  return stats ? go(pathKernel<kModeCounts, true, false>) : go(pathKernel<kModeCounts, false, false>);
 }
 
 // PTX_WIDE=0 in the environment keeps the radiance path on the binary layout (A/B measurements).
@@ -259,31 +333,32 @@ bool useWide(const ptx_scene* s) {
   return s->wideStackBound != 0u && !(env && env[0] == '0');
 }
 
-int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool resolve, hipStream_t stream, bool stats) {
+int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool resolve, hipStream_t stream, bool stats,
+                   ScratchOwner owner = ScratchOwner::handle) {
   const bool wide = useWide(s);
-  auto launch = [&](void* out) {
-    if (wide) return stats ? launchPath(s, pathKernel<kModeRadiance, true, true>, fc, out, stream, true)
-                           : launchPath(s, pathKernel<kModeRadiance, false, true>, fc, out, stream, true);
-    return stats ? launchPath(s, pathKernel<kModeRadiance, true, false>, fc, out, stream)
-                 : launchPath(s, pathKernel<kModeRadiance, false, false>, fc, out, stream);
-  };
-  if (fc.subStreams == 1u && !resolve) return launch(dOut);  // the kernel writes (sum, samples) itself
-  // every stream of a pixel is a work item of its own and writes its own plane; the planes are added in
-  // stream order afterwards (deterministic, unlike float atomics), and resolved if the caller wants pixels
+  // with one stream and no resolve the kernel writes (sum, samples) itself; otherwise every stream of a
+  // pixel is a work item of its own and writes its own plane, and the planes are added in stream order
+  // afterwards (deterministic, unlike float atomics), and resolved if the caller wants pixels
+  const bool direct = fc.subStreams == 1u && !resolve;
   const uint32_t nPixels = fc.width * fc.height;
-  const size_t bytes = (size_t)fc.subStreams * nPixels * sizeof(float4);
-  if (s->planeBytes < bytes) {
-    if (s->dPlanes) HIP_TRY(hipFree(s->dPlanes));
-    s->dPlanes = nullptr;
-    s->planeBytes = 0;
-    HIP_TRY(hipMalloc((void**)&s->dPlanes, bytes));
-    s->planeBytes = bytes;
-  }
-  int rc = launch(s->dPlanes);
-  if (rc) return rc;
-  combineKernel<<<dim3((nPixels + 255u) / 256u), dim3(256), 0, stream>>>(s->dPlanes, fc.subStreams, nPixels, dOut, resolve);
-  HIP_TRY(hipGetLastError());
-  return PTX_OK;
+  auto go = [&](auto kernel) {
+    LaunchPlan plan;
+    Scratch scr;
+    int rc = planLaunch(s, kernel, fc, wide, plan);
+    if (rc) return rc;
+    plan.planeBytes = direct ? 0u : (size_t)fc.subStreams * nPixels * sizeof(float4);
+    (void)owner;
+    rc = handleScratch(s, plan, scr);
+    if (rc) return rc;
+    if ((rc = launchPath(s, kernel, fc, plan, scr, direct ? (void*)dOut : (void*)scr.planes, stream))) return rc;
+    if (!direct) {
+      combineKernel<<<dim3((nPixels + 255u) / 256u), dim3(256), 0, stream>>>(scr.planes, fc.subStreams, nPixels, dOut, resolve);
+      HIP_TRY(hipGetLastError());
+    }
+    return (int)PTX_OK;
+  };
+  if (wide) return stats ? go(pathKernel<kModeRadiance, true, true>) : go(pathKernel<kModeRadiance, false, true>);
+  return stats ? go(pathKernel<kModeRadiance, true, false>) : go(pathKernel<kModeRadiance, false, false>);
 }
 
 int kernelSeconds(ptx_scene* s, double* out) {
@@ -292,6 +367,17 @@ int kernelSeconds(ptx_scene* s, double* out) {
   float ms = 0.0f;
   HIP_TRY(hipEventElapsedTime(&ms, s->evStart, s->evStop));
   *out = (double)ms * 1e-3;
+  return PTX_OK;
+}
+
+// A part of a sample-slice split that received no samples (more parts than samples): its accumulation
+// buffer is all zeros -- (sum, samples) = 0 -- so that the collective still has a contribution from every
+// rank.  Returns 0 if handled, a negative error, or 1 if the call is an ordinary one.
+int emptyShare(ptx_scene* s, const ptx_params* prm, float* dAccum, hipStream_t stream) {
+  if (!s || !prm || prm->spp != 0u || prm->frame_spp == 0u) return 1;
+  if (!dAccum || prm->width == 0 || prm->height == 0) return fail(PTX_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemsetAsync(dAccum, 0, (size_t)prm->width * prm->height * sizeof(float4), stream));
   return PTX_OK;
 }
 
@@ -383,9 +469,9 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
   uint32_t wideStackBound = 3u * (tlasWide.depth + blasWideDepth) + 2u + 4u;
   if (wideStackBound > kStackEntries) wideStackBound = 0u;  // radiance stays on the binary layout
 
-  if (tlas.depth + blasDepth + 2u > kStackEntries) {  // sanity bound on the overflow area
+  if (binaryStackBound(tlas.depth, blasDepth) > kStackEntries) {  // sanity bound on the overflow area
     char buf[160];
-    snprintf(buf, sizeof(buf), "BVH too deep for the traversal stack: TLAS depth %u + BLAS depth %u + 2 > %u", tlas.depth,
+    snprintf(buf, sizeof(buf), "BVH too deep for the traversal stack: TLAS depth %u + BLAS depth %u + 3 > %u", tlas.depth,
              blasDepth, kStackEntries);
     return fail(PTX_ELIMIT, buf);
   }
@@ -682,8 +768,9 @@ int ptx_render_counts(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm
 
 int ptx_accumulate_device(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, float* dAccum, void* stream) {
   FrameConstants fc;
-  int rc = makeFrame(s, cam, prm, false, fc);
-  if (rc) return rc;
+  int rc = emptyShare(s, prm, dAccum, (hipStream_t)stream);
+  if (rc <= 0) return rc;
+  if ((rc = makeFrame(s, cam, prm, false, fc))) return rc;
   if (!dAccum) return fail(PTX_EINVAL, "null output");
   if ((uintptr_t)dAccum & 15u) return fail(PTX_EINVAL, "d_accum must be 16-byte aligned");
   HIP_TRY(hipSetDevice(s->device));

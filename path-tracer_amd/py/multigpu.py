@@ -63,12 +63,18 @@ class HipBackend:
         self.dscene.close()
 
 
-def render_radiance(backend, make_params, width, height, spp_this_rank, max_bounces, rank, world, dist=None):
-    """One frame.  Returns the tonemapped (H, W, 3) tensor on rank 0, None elsewhere."""
+def render_radiance(backend, make_params, width, height, frame_spp, max_bounces, rank, world, dist=None, sub_streams=0):
+    """One frame of `frame_spp` samples per pixel, split over the ranks (strong scaling: the job does not
+    grow with the number of GPUs).  Returns the tonemapped (H, W, 3) tensor on rank 0, None elsewhere.
+
+    Every rank tells the backend the FRAME's sample count (ptx_params.frame_spp): whether camera rays are
+    jittered is a property of the frame (gpuRender.cu:134), not of a rank's share, and a rank whose share is
+    empty (more ranks than samples) still contributes an all-zero buffer to the reduce."""
     import ptamd
-    seed_mode = ptamd.SEED_REFERENCE_GPU if world == 1 else ptamd.SEED_STREAM
-    params = make_params(width, height, spp=spp_this_rank, max_bounces=max_bounces, seed_mode=seed_mode,
-                         part_index=rank, part_count=world)
+    seed_mode = ptamd.SEED_REFERENCE_GPU if world == 1 and sub_streams <= 1 else ptamd.SEED_STREAM
+    params = make_params(width, height, spp=split_samples(frame_spp, world)[rank], max_bounces=max_bounces,
+                         seed_mode=seed_mode, part_index=rank, part_count=world, sub_streams=sub_streams,
+                         frame_spp=frame_spp)
     accum = backend.accumulate(params)
     if world > 1:
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)

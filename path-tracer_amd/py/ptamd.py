@@ -81,7 +81,7 @@ class Camera(C.Structure):
 class Params(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32),
                 ("max_bounces", C.c_uint32), ("seed_mode", C.c_uint32), ("part_index", C.c_uint32),
-                ("part_count", C.c_uint32), ("sub_streams", C.c_uint32)]
+                ("part_count", C.c_uint32), ("sub_streams", C.c_uint32), ("frame_spp", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -102,8 +102,8 @@ class HostInfo(C.Structure):
 
 
 def make_params(width, height, spp=1, max_bounces=1, seed_mode=SEED_REFERENCE_GPU, part_index=0, part_count=1,
-                sub_streams=0):
-    return Params(width, height, spp, max_bounces, seed_mode, part_index, part_count, sub_streams)
+                sub_streams=0, frame_spp=0):
+    return Params(width, height, spp, max_bounces, seed_mode, part_index, part_count, sub_streams, frame_spp)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -42,7 +42,7 @@ def test_struct_sizes_match_the_reference_layouts():
     assert C.sizeof(ptamd.Triangle) == 36
     assert C.sizeof(ptamd.Instance) == 136
     assert C.sizeof(ptamd.Geometry) == 32
-    assert C.sizeof(ptamd.Params) == 32
+    assert C.sizeof(ptamd.Params) == 36
 
 
 def test_backend_rejects_bad_arguments_without_a_gpu():

@@ -20,7 +20,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     j = json.loads(lines[0])
     assert j["metric"] == "Mrays/s at 1500x800, 100spp, 6 bounces, Scene 1" and j["unit"] == "Mrays/s"
     assert j["n_gpus"] == 1 and j["steps"] == 1 and j["warmup"] == 1 and j["higher_is_better"] is True
-    assert j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "f32" and j["data"] == "synthetic"
+    assert j["scaling"] == "strong" and j["vs_baseline"] is None and j["dtype"] == "f32" and j["data"] == "synthetic"
     assert j["value"] > 0 and j["ms_per_step"] > 0
     assert "workload" in j["config"] and "model" not in j["config"]
     r = j["roofline"]
