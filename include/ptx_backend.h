@@ -219,6 +219,23 @@ int ptx_resolve_device(ptx_scene* scene, const float* d_accum, uint32_t width, u
 int ptx_counts_device(ptx_scene* scene, const ptx_camera* camera, const ptx_params* params,
                       uint32_t* d_counts, void* hip_stream);
 
+/* ptx_accumulate_device for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE (renderGPU
+ * allocates everything per call, gpuRender.cu:188-262): this is for code under HIP graph capture, tight
+ * serving loops and harnesses that forbid hipMalloc.  Same arguments, same kernels and bit-identical
+ * output, but the device memory the launch needs beyond the scene, the input and d_accum -- the work
+ * counter, the traversal-stack overflow area, and (sub_streams > 1) the per-stream accumulation planes
+ * -- comes from ONE static array of PTX_NOALLOC_SCRATCH_BYTES that the library holds on every GPU it
+ * runs on until the process ends; the call makes no hipMalloc / hipFree.  A launch that needs more
+ * (planes = sub_streams * width * height * 16 bytes; the overflow area is at most 91 MB for the preset scenes:
+ * (stack bound - 26) * 4 bytes per lane of the persistent grid, scene 1 on the wide layout)
+ * fails with PTX_ELIMIT and a message that names the numbers.  All calls on one GPU share that GPU's
+ * array, whatever the scene handle: calls that overlap on one GPU (two streams, two threads) race;
+ * calls ordered on one stream do not.  Requires a handle from ptx_create on the same device (that is
+ * where the array's device address is resolved). */
+#define PTX_NOALLOC_SCRATCH_BYTES (128u << 20)
+int ptx_accumulate_device_noalloc(ptx_scene* scene, const ptx_camera* camera, const ptx_params* params,
+                                  float* d_accum, void* hip_stream);
+
 /* Statistics of the most recent render on this scene, gathered by an instrumented (slower) variant
  * of the kernels: call with the same camera/params as the render it describes; paths are
  * deterministic in (pixel, seed), so the numbers apply to the un-instrumented launch exactly. */

@@ -20,6 +20,11 @@
 
 using namespace ptx;
 
+// Scratch of ptx_accumulate_device_noalloc (include/ptx_backend.h): one array per GPU, held until the
+// process ends.  In host code this name is only a handle for hipGetSymbolAddress; the device address is
+// resolved once per device in ptx_create (scratchOnDevice) and kernels receive it as an argument.
+static __device__ __align__(256) unsigned char gNoAllocScratch[PTX_NOALLOC_SCRATCH_BYTES];
+
 namespace {
 
 thread_local std::string g_error;
@@ -39,6 +44,24 @@ int fail(int code, const std::string& msg) {
       return fail(PTX_EHIP, buf_);                                                                  \
     }                                                                                               \
   } while (0)
+
+// Device address of gNoAllocScratch on `device` (which must be the current device): every GPU holds
+// its own copy of the array at its own address.
+constexpr int kMaxDevices = 64;
+int scratchOnDevice(int device, unsigned char** out) {
+  static std::mutex mu;
+  static unsigned char* ptrs[kMaxDevices] = {};
+  if (device < 0 || device >= kMaxDevices) return fail(PTX_EINVAL, "device index out of range");
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ptrs[device]) {
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(gNoAllocScratch)));
+    if (!p || ((uintptr_t)p & 255u)) return fail(PTX_EHIP, "hipGetSymbolAddress returned an unusable address for the static scratch array");
+    ptrs[device] = static_cast<unsigned char*>(p);
+  }
+  *out = ptrs[device];
+  return PTX_OK;
+}
 
 struct TreeInfo {
   uint32_t rootRef = 0;
@@ -147,6 +170,7 @@ struct ptx_scene {
   size_t rowsBytes = 0;
   float4* dPlanes = nullptr;  // per-stream accumulation planes of a sub-stream launch
   size_t planeBytes = 0;
+  unsigned char* staticScratch = nullptr;  // this device's copy of gNoAllocScratch (resolved in ptx_create)
 };
 
 namespace {
@@ -313,6 +337,27 @@ int handleScratch(ptx_scene* s, const LaunchPlan& plan, Scratch& scr) {
   return PTX_OK;
 }
 
+// The library's static scratch array (ptx_accumulate_device_noalloc): header | overflow | planes, each
+// 256-byte aligned.  Nothing is allocated; a launch that needs more than the array holds is refused.
+int staticScratch(ptx_scene* s, const LaunchPlan& plan, Scratch& scr) {
+  if (!s->staticScratch) return fail(PTX_EHIP, "the static scratch array was not resolved on this device");
+  auto up256 = [](size_t v) { return (v + 255u) & ~size_t(255); };
+  const size_t oOvf = 256u, oPlanes = oOvf + up256(plan.ovfBytes), need = oPlanes + up256(plan.planeBytes);
+  if (need > (size_t)PTX_NOALLOC_SCRATCH_BYTES) {
+    char buf[256];
+    snprintf(buf, sizeof(buf),
+             "ptx_accumulate_device_noalloc: this launch needs %zu bytes of scratch (stack overflow area %zu + stream planes %zu), "
+             "the static array holds %zu: use fewer sub_streams / a smaller frame, or ptx_accumulate_device",
+             need, plan.ovfBytes, plan.planeBytes, (size_t)PTX_NOALLOC_SCRATCH_BYTES);
+    return fail(PTX_ELIMIT, buf);
+  }
+  unsigned char* base = s->staticScratch;
+  scr.workCounter = reinterpret_cast<uint32_t*>(base);
+  scr.overflow = reinterpret_cast<uint32_t*>(base + oOvf);
+  scr.planes = reinterpret_cast<float4*>(base + oPlanes);
+  return PTX_OK;
+}
+
 enum class ScratchOwner { handle, library };
 
 int launchCounts(ptx_scene* s, const FrameConstants& fc, uint32_t* dOut, hipStream_t stream, bool stats) {
@@ -347,8 +392,7 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
     int rc = planLaunch(s, kernel, fc, wide, plan);
     if (rc) return rc;
     plan.planeBytes = direct ? 0u : (size_t)fc.subStreams * nPixels * sizeof(float4);
-    (void)owner;
-    rc = handleScratch(s, plan, scr);
+    rc = owner == ScratchOwner::library ? staticScratch(s, plan, scr) : handleScratch(s, plan, scr);
     if (rc) return rc;
     if ((rc = launchPath(s, kernel, fc, plan, scr, direct ? (void*)dOut : (void*)scr.planes, stream))) return rc;
     if (!direct) {
@@ -613,6 +657,17 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
   D.envHeight = d->env_height;
   s->tlasDepth = tlas.depth;
   s->blasDepth = blasDepth;
+  // set-up for the no-allocation entry point: this device's address of the static scratch array, and
+  // the occupancy of the kernels it launches (so that the call itself makes no runtime query)
+  rc = scratchOnDevice(device, &s->staticScratch);
+  uint32_t blocks = 0;
+  if (!rc) rc = persistentGrid(s, pathKernel<kModeRadiance, false, true>, blocks);
+  if (!rc) rc = persistentGrid(s, pathKernel<kModeRadiance, false, false>, blocks);
+  if (rc) {
+    std::string msg = g_error;
+    ptx_destroy(s);
+    return fail(rc, msg);
+  }
   s->uploadSeconds = nowSeconds() - t0;
   *out = s;
   return PTX_OK;
@@ -775,6 +830,17 @@ int ptx_accumulate_device(ptx_scene* s, const ptx_camera* cam, const ptx_params*
   if ((uintptr_t)dAccum & 15u) return fail(PTX_EINVAL, "d_accum must be 16-byte aligned");
   HIP_TRY(hipSetDevice(s->device));
   return launchRadiance(s, fc, dAccum, false, (hipStream_t)stream, false);
+}
+
+int ptx_accumulate_device_noalloc(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, float* dAccum, void* stream) {
+  FrameConstants fc;
+  int rc = emptyShare(s, prm, dAccum, (hipStream_t)stream);
+  if (rc <= 0) return rc;
+  if ((rc = makeFrame(s, cam, prm, false, fc))) return rc;
+  if (!dAccum) return fail(PTX_EINVAL, "null output");
+  if ((uintptr_t)dAccum & 15u) return fail(PTX_EINVAL, "d_accum must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(s->device));
+  return launchRadiance(s, fc, dAccum, false, (hipStream_t)stream, false, ScratchOwner::library);
 }
 
 int ptx_resolve_device(ptx_scene* s, const float* dAccum, uint32_t width, uint32_t height, float* dOut, void* stream) {

@@ -249,8 +249,9 @@ BACKEND_SYMBOLS = [
     "ptx_device_count", "ptx_create", "ptx_render_counts", "ptx_render", "ptx_accumulate_device",
     "ptx_resolve_device", "ptx_counts_device", "ptx_measure", "ptx_last_kernel_seconds", "ptx_destroy",
     "ptx_last_error", "ptx_version", "ptx_check_wide_layout", "ptx_selftest_reciprocal", "ptx_render_counts_bgr8",
-    "ptx_render_bgr8",
+    "ptx_render_bgr8", "ptx_accumulate_device_noalloc",
 ]
+NOALLOC_SCRATCH_BYTES = 128 << 20  # PTX_NOALLOC_SCRATCH_BYTES
 
 
 def backend_lib():
@@ -268,6 +269,7 @@ def backend_lib():
         lib.ptx_render_counts.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.POINTER(Stats)]
         lib.ptx_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.POINTER(Stats)]
         lib.ptx_accumulate_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, vp]
+        lib.ptx_accumulate_device_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, vp]
         lib.ptx_resolve_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp]
         lib.ptx_counts_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, vp]
         lib.ptx_measure.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), C.c_int, C.POINTER(Stats)]
@@ -347,6 +349,11 @@ class DeviceScene:
     def accumulate_device(self, camera, params, d_accum_ptr, stream=None):
         _check(backend_lib().ptx_accumulate_device(self._h, C.byref(camera), C.byref(params), d_accum_ptr, stream),
                "ptx_accumulate_device")
+
+    def accumulate_device_noalloc(self, camera, params, d_accum_ptr, stream=None):
+        """ptx_accumulate_device on the library's static scratch array: no hipMalloc / hipFree in the call."""
+        _check(backend_lib().ptx_accumulate_device_noalloc(self._h, C.byref(camera), C.byref(params), d_accum_ptr, stream),
+               "ptx_accumulate_device_noalloc")
 
     def resolve_device(self, d_accum_ptr, width, height, d_out_ptr, stream=None):
         _check(backend_lib().ptx_resolve_device(self._h, d_accum_ptr, width, height, d_out_ptr, stream),
