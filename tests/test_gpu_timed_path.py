@@ -5,11 +5,13 @@ last configuration is scene 1 at 3840x2160, 8 bounces, split over 8 GPUs.  The t
 those code paths through the C ABI against the CPU oracle:
 
  * same seeds: sub-stream launch on scene 1 == the sum of the oracle's streams.  Tolerance (tonemapped
-   [0,1] units): per-pixel RMSE < 3e-2, >= 85 % of the pixels within 2e-3, |mean difference| < 2e-3.
-   The per-pixel allowance is loose because scene 1 is full of metal (GGX with roughness 0.05-0.2): a
-   1-ulp difference between glibc's and the device library's cosf/sinf/powf moves the next bounce, and
-   a long specular chain amplifies it; such a pixel gets another sample of the SAME distribution, which
-   is what the high-spp tests below check.
+   [0,1] units): per-pixel RMSE < 3e-2, |mean difference| < 2e-3, and at most 2 % of the PATHS may part
+   from the oracle's: a pixel of n samples must be within 2e-3 with probability >= 0.98^n (scene 0:
+   >= 99 % of the pixels outright).  Scene 1 is 10,000 small curved busts, half of them metal (GGX,
+   roughness 0.05-0.2): a 1-ulp difference between glibc's and the device library's cosf/sinf/powf
+   moves the next bounce, every curved mirror amplifies it, and after a few bounces the path hits
+   another triangle (measured: 0.6 % of the paths at 6 bounces, 1.4 % at 8).  Such a path is another
+   sample of the SAME distribution, which is what the high-spp tests below check.
  * different seeds, high spp (north_star: "a stated per-pixel RMSE at high spp"): the GPU frame with
    the bench's seeding (RNG sub-streams, wide layout) against the oracle with the reference CPU path's
    own seeding (`-d 1 -t 1`), scenes 0 and 1, 512 spp, 6 bounces.  Two independent estimates can only
@@ -68,7 +70,7 @@ def test_sub_streams_on_the_timed_scene_match_the_oracle_streams(gpu_scenes, pre
     print(f"scene {preset} {W}x{H} {spp} spp in {streams} streams: rmse {rmse(a, b):.2e}, within 2e-3: {(d < 2e-3).mean():.4f}, "
           f"mean diff {float(a.mean() - b.mean()):+.2e}")
     assert rmse(a, b) < 3e-2
-    assert (d < 2e-3).mean() >= 0.85
+    assert (d < 2e-3).mean() >= (0.98 ** spp if preset == 1 else 0.99)
     assert abs(float(a.mean() - b.mean())) < 2e-3
     st = devs[preset].measure(hosts[preset].camera, p)
     assert abs(int(st.rays) - int(rays)) <= max(8, int(0.02 * rays))
@@ -141,7 +143,7 @@ def test_same_seed_images_agree_with_8_bounces(gpu_scenes, preset, size, spp):
     got, _ = devs[preset].render(hosts[preset].camera, p)
     d = np.abs(got - ref).max(axis=2)
     print(f"scene {preset} 8 bounces: rmse {rmse(got, ref):.2e}, within 2e-3: {(d < 2e-3).mean():.4f}")
-    tol_rmse, tol_frac = (3e-2, 0.85) if preset == 1 else (2e-3, 0.99)
+    tol_rmse, tol_frac = (3e-2, 0.98 ** spp) if preset == 1 else (2e-3, 0.99)  # see the module docstring
     assert rmse(got, ref) < tol_rmse and (d < 2e-3).mean() >= tol_frac
     st = devs[preset].measure(hosts[preset].camera, p)
     assert abs(int(st.rays) - int(st_ref.rays)) <= max(8, int(0.02 * st_ref.rays))
