@@ -130,7 +130,7 @@ def test_c5_shape_radiance_at_3840x2160_8_bounces(gpu_scenes):
     assert img.min() >= 0.0 and img.max() <= 1.0 and img.std() > 0.01
     b = _accumulate(devs[1], hosts[1], p, torch)
     assert np.array_equal(a, b)  # repeatable: no float atomics, planes added in stream order
-    # a window of the frame against the oracle's two streams (same seeds): the oracle renders the window's rows only
+    # every ray ends in a shaded hit or an environment lookup; every path has at least its camera ray
     st = devs[1].measure(hosts[1].camera, p)
     assert st.hits + st.misses == st.rays and st.rays >= 2 * W * H
 
