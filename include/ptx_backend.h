@@ -219,6 +219,24 @@ int ptx_resolve_device(ptx_scene* scene, const float* d_accum, uint32_t width, u
 int ptx_counts_device(ptx_scene* scene, const ptx_camera* camera, const ptx_params* params,
                       uint32_t* d_counts, void* hip_stream);
 
+/* One process, several GPUs (no counterpart in the reference; SURVEY.md section 5: "-g <ngpus>"):
+ * scenes[i] is a handle that ptx_create made on the i-th device to use (the scene is replicated).
+ *   ptx_render_multi        : `params` describes the WHOLE frame (spp = samples per pixel of the frame).  Part i
+ *                             traces spp / count (+1 for the first spp % count) samples of every pixel with RNG
+ *                             stream set i (sample-slice split; count > 1 requires PTX_SEED_STREAM) on its own
+ *                             stream, all devices at once; the W*H*4 f32 accumulation buffers are copied
+ *                             device-to-device (hipMemcpyPeerAsync, xGMI) into the first handle's device, added
+ *                             there in part order, divided by the summed sample count, graded and tonemapped.
+ *                             Same result as N processes with one RCCL reduce (multigpu.py); count = 1 equals
+ *                             ptx_render.
+ *   ptx_render_counts_multi : heat map, 8x8-tile partition (tile % count == i), integer sum on the first device:
+ *                             bit-identical to ptx_render_counts.
+ * stats->render_s is the wall time of the whole job (slowest part + gather + resolve + copy back). */
+int ptx_render_multi(ptx_scene* const* scenes, uint32_t count, const ptx_camera* camera, const ptx_params* params,
+                     float* out_rgb, ptx_stats* stats /* may be NULL */);
+int ptx_render_counts_multi(ptx_scene* const* scenes, uint32_t count, const ptx_camera* camera, const ptx_params* params,
+                            uint32_t* out_counts, ptx_stats* stats /* may be NULL */);
+
 /* ptx_accumulate_device for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE (renderGPU
  * allocates everything per call, gpuRender.cu:188-262): this is for code under HIP graph capture, tight
  * serving loops and harnesses that forbid hipMalloc.  Same arguments, same kernels and bit-identical

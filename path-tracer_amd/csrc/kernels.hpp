@@ -46,7 +46,7 @@ constexpr uint32_t kBlockThreads = 256;  // 4 waves
 #define PTX_LDS_STACK 26
 #endif
 #ifndef PTX_MIN_WAVES
-#define PTX_MIN_WAVES 6
+#define PTX_MIN_WAVES 5
 #endif
 constexpr uint32_t kLdsStack = PTX_LDS_STACK;  // stack entries per lane kept in LDS (1 KB per entry per block)
 // Tunables (see DESIGN.md "Scheduling inside a wave").
@@ -524,6 +524,17 @@ __global__ void __launch_bounds__(256) combineKernel(const float4* __restrict__ 
   } else {
     reinterpret_cast<float4*>(out)[i] = a;
   }
+}
+
+// Tile-partitioned heat map (ptx_render_counts_multi): every pixel is non-zero in at most one part, so the
+// integer sum reassembles the frame exactly.
+__global__ void __launch_bounds__(256) sumCountsKernel(const uint32_t* __restrict__ parts, uint32_t nParts, uint32_t nPixels,
+                                                       uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nPixels) return;
+  uint32_t c = parts[i];
+  for (uint32_t k = 1; k < nParts; k++) c += parts[(size_t)k * nPixels + i];
+  out[i] = c;
 }
 
 // ---- device-side output stage (main.cpp:363-374, output.cpp:13-23) ----

@@ -16,6 +16,9 @@
 
 #include "device_scene.hpp"
 #include "kernels.hpp"
+#ifdef PTX_EXPERIMENT_PHASES  // DESIGN.md section 3, "phase kernel": measured slower, kept for A/B builds only
+#include "radiance_kernel.hpp"
+#endif
 #include "wide_bvh.hpp"
 
 using namespace ptx;
@@ -171,6 +174,12 @@ struct ptx_scene {
   float4* dPlanes = nullptr;  // per-stream accumulation planes of a sub-stream launch
   size_t planeBytes = 0;
   unsigned char* staticScratch = nullptr;  // this device's copy of gNoAllocScratch (resolved in ptx_create)
+  // ptx_render_multi / ptx_render_counts_multi: this handle's own stream and "my part is on the root" event,
+  // and (root handle only) the buffer the parts are gathered into
+  hipStream_t ownStream = nullptr;
+  hipEvent_t evPart = nullptr;
+  void* dGather = nullptr;
+  size_t gatherBytes = 0;
 };
 
 namespace {
@@ -286,19 +295,20 @@ struct LaunchPlan {
 };
 
 template <typename K>
-int planLaunch(ptx_scene* s, K kernel, const FrameConstants& fc, bool wide, LaunchPlan& plan) {
+int planLaunch(ptx_scene* s, K kernel, const FrameConstants& fc, bool wide, uint32_t ldsStack, uint32_t raysPerLane, LaunchPlan& plan) {
   uint32_t blocks = 0;
   int rc = persistentGrid(s, kernel, blocks);
   if (rc) return rc;
   // one lane per work item: pixels x RNG streams (checked in makeFrame to fit 32 bits)
   const uint32_t work = fc.width * fc.height * fc.subStreams;
-  const uint32_t needed = (work + kBlockThreads - 1u) / kBlockThreads;
+  const uint32_t perBlock = kBlockThreads * raysPerLane;
+  const uint32_t needed = (work + perBlock - 1u) / perBlock;
   if (blocks > needed) blocks = needed;
   const uint32_t bound = wide ? s->wideStackBound : binaryStackBound(s->tlasDepth, s->blasDepth);
-  const size_t deepEntries = bound > kLdsStack ? bound - kLdsStack : 0u;
+  const size_t deepEntries = bound > ldsStack ? bound - ldsStack : 0u;  // entries beyond the kernel's LDS part
   plan.blocks = blocks;
   plan.wide = wide;
-  plan.ovfBytes = (deepEntries ? deepEntries : 1u) * (size_t)blocks * kBlockThreads * sizeof(uint32_t);
+  plan.ovfBytes = (deepEntries ? deepEntries : 1u) * (size_t)raysPerLane * blocks * kBlockThreads * sizeof(uint32_t);
   return PTX_OK;
 }
 
@@ -364,7 +374,7 @@ int launchCounts(ptx_scene* s, const FrameConstants& fc, uint32_t* dOut, hipStre
   auto go = [&](auto kernel) {
     LaunchPlan plan;
     Scratch scr;
-    int rc = planLaunch(s, kernel, fc, false, plan);
+    int rc = planLaunch(s, kernel, fc, false, kLdsStack, 1u, plan);
     if (!rc) rc = handleScratch(s, plan, scr);
     if (!rc) rc = launchPath(s, kernel, fc, plan, scr, dOut, stream);
     return rc;
@@ -386,10 +396,10 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
   // afterwards (deterministic, unlike float atomics), and resolved if the caller wants pixels
   const bool direct = fc.subStreams == 1u && !resolve;
   const uint32_t nPixels = fc.width * fc.height;
-  auto go = [&](auto kernel) {
+  auto go = [&](auto kernel, uint32_t ldsStack, uint32_t raysPerLane = 1u) {
     LaunchPlan plan;
     Scratch scr;
-    int rc = planLaunch(s, kernel, fc, wide, plan);
+    int rc = planLaunch(s, kernel, fc, wide, ldsStack, raysPerLane, plan);
     if (rc) return rc;
     plan.planeBytes = direct ? 0u : (size_t)fc.subStreams * nPixels * sizeof(float4);
     rc = owner == ScratchOwner::library ? staticScratch(s, plan, scr) : handleScratch(s, plan, scr);
@@ -401,8 +411,13 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
     }
     return (int)PTX_OK;
   };
-  if (wide) return stats ? go(pathKernel<kModeRadiance, true, true>) : go(pathKernel<kModeRadiance, false, true>);
-  return stats ? go(pathKernel<kModeRadiance, true, false>) : go(pathKernel<kModeRadiance, false, false>);
+#ifdef PTX_EXPERIMENT_PHASES
+  // experimental builds: the phase kernel (radiance_kernel.hpp) unless PTX_RAD_LEGACY=1
+  static const char* legacy = getenv("PTX_RAD_LEGACY");
+  if (wide && !(legacy && legacy[0] == '1')) return stats ? go(radianceKernel<true>, kRadStack, kRadRays) : go(radianceKernel<false>, kRadStack, kRadRays);
+#endif
+  if (wide) return stats ? go(pathKernel<kModeRadiance, true, true>, kLdsStack) : go(pathKernel<kModeRadiance, false, true>, kLdsStack);
+  return stats ? go(pathKernel<kModeRadiance, true, false>, kLdsStack) : go(pathKernel<kModeRadiance, false, false>, kLdsStack);
 }
 
 int kernelSeconds(ptx_scene* s, double* out) {
@@ -661,6 +676,9 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
   // the occupancy of the kernels it launches (so that the call itself makes no runtime query)
   rc = scratchOnDevice(device, &s->staticScratch);
   uint32_t blocks = 0;
+#ifdef PTX_EXPERIMENT_PHASES
+  if (!rc) rc = persistentGrid(s, radianceKernel<false>, blocks);
+#endif
   if (!rc) rc = persistentGrid(s, pathKernel<kModeRadiance, false, true>, blocks);
   if (!rc) rc = persistentGrid(s, pathKernel<kModeRadiance, false, false>, blocks);
   if (rc) {
@@ -789,6 +807,9 @@ void ptx_destroy(ptx_scene* s) {
   if (s->dOverflow) (void)hipFree(s->dOverflow);
   if (s->dRows) (void)hipFree(s->dRows);
   if (s->dPlanes) (void)hipFree(s->dPlanes);
+  if (s->dGather) (void)hipFree(s->dGather);
+  if (s->ownStream) (void)hipStreamDestroy(s->ownStream);
+  if (s->evPart) (void)hipEventDestroy(s->evPart);
   if (s->evStart) (void)hipEventDestroy(s->evStart);
   if (s->evStop) (void)hipEventDestroy(s->evStop);
   delete s;
@@ -936,6 +957,138 @@ int ptx_render_bgr8(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, 
   return PTX_OK;
 }
 
+namespace {
+
+// Split of a frame's samples over `parts`: the first (spp % parts) parts take one more (the same rule as
+// path-tracer_amd/py/multigpu.py: split_samples).
+uint32_t shareOf(uint32_t spp, uint32_t parts, uint32_t part) { return spp / parts + (part < spp % parts ? 1u : 0u); }
+
+int multiSetup(ptx_scene* const* scenes, uint32_t count, size_t gatherBytes) {
+  if (!scenes || count == 0 || count > 64) return fail(PTX_EINVAL, "ptx_*_multi: need 1..64 scene handles");
+  for (uint32_t i = 0; i < count; i++) {
+    ptx_scene* s = scenes[i];
+    if (!s) return fail(PTX_EINVAL, "ptx_*_multi: null scene handle");
+    for (uint32_t j = 0; j < i; j++)
+      if (scenes[j] == s) return fail(PTX_EINVAL, "ptx_*_multi: a scene handle is listed twice (one launch per handle may be in flight)");
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->ownStream) HIP_TRY(hipStreamCreateWithFlags(&s->ownStream, hipStreamNonBlocking));
+    if (!s->evPart) HIP_TRY(hipEventCreateWithFlags(&s->evPart, hipEventDisableTiming));
+  }
+  ptx_scene* root = scenes[0];
+  HIP_TRY(hipSetDevice(root->device));
+  if (root->gatherBytes < gatherBytes) {
+    if (root->dGather) HIP_TRY(hipFree(root->dGather));
+    root->dGather = nullptr;
+    root->gatherBytes = 0;
+    HIP_TRY(hipMalloc(&root->dGather, gatherBytes));
+    root->gatherBytes = gatherBytes;
+  }
+  return PTX_OK;
+}
+
+// part i's buffer (on its own device) -> plane i of the root's gather buffer; the root's stream then waits for it
+int sendToRoot(ptx_scene* root, ptx_scene* part, uint32_t index, const void* src, size_t bytes) {
+  HIP_TRY(hipSetDevice(part->device));
+  HIP_TRY(hipMemcpyPeerAsync((char*)root->dGather + (size_t)index * bytes, root->device, src, part->device, bytes, part->ownStream));
+  HIP_TRY(hipEventRecord(part->evPart, part->ownStream));
+  HIP_TRY(hipSetDevice(root->device));
+  HIP_TRY(hipStreamWaitEvent(root->ownStream, part->evPart, 0));
+  return PTX_OK;
+}
+
+}  // namespace
+
+int ptx_render_multi(ptx_scene* const* scenes, uint32_t count, const ptx_camera* cam, const ptx_params* frame, float* out,
+                     ptx_stats* stats) {
+  if (!cam || !frame || !out) return fail(PTX_EINVAL, "null argument");
+  if (count > 1 && frame->seed_mode != PTX_SEED_STREAM)
+    return fail(PTX_EINVAL, "ptx_render_multi: more than one GPU needs PTX_SEED_STREAM (one RNG stream set per GPU)");
+  if (frame->spp == 0) return fail(PTX_EINVAL, "spp must be > 0");
+  const size_t nPixels = (size_t)frame->width * frame->height;
+  const size_t plane = nPixels * sizeof(float4);
+  int rc = multiSetup(scenes, count, plane * count);
+  if (rc) return rc;
+  ptx_scene* root = scenes[0];
+  const double t0 = nowSeconds();
+  for (uint32_t i = 0; i < count; i++) {
+    ptx_scene* s = scenes[i];
+    ptx_params p = *frame;
+    p.spp = shareOf(frame->spp, count, i);
+    p.frame_spp = frame->spp;
+    p.part_index = frame->part_index * count + i;  // a frame that is itself a part of a larger job keeps distinct streams
+    p.part_count = (frame->part_count > 1u ? frame->part_count : 1u) * count;
+    HIP_TRY(hipSetDevice(s->device));
+    // part 0 accumulates straight into plane 0 of the gather buffer; the others into their own buffer, then copy
+    float* dst = (float*)root->dGather;
+    if (i != 0) {
+      if ((rc = ensureOut(s, plane))) return rc;
+      dst = (float*)s->outBuf;
+    }
+    rc = emptyShare(s, &p, dst, s->ownStream);
+    if (rc < 0) return rc;
+    if (rc > 0) {
+      FrameConstants fc;
+      if ((rc = makeFrame(s, cam, &p, false, fc))) return rc;
+      if ((rc = launchRadiance(s, fc, dst, false, s->ownStream, false))) return rc;
+    }
+    if (i != 0 && (rc = sendToRoot(root, s, i, dst, plane))) return rc;
+  }
+  // root: add the parts in part order, divide by the summed sample count, grade, tonemap (gpuRender.cu:158-169)
+  HIP_TRY(hipSetDevice(root->device));
+  if ((rc = ensureOut(root, nPixels * 3u * sizeof(float)))) return rc;
+  combineKernel<<<dim3((uint32_t)((nPixels + 255u) / 256u)), dim3(256), 0, root->ownStream>>>((const float4*)root->dGather, count,
+                                                                                                (uint32_t)nPixels, root->outBuf, true);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, root->outBuf, nPixels * 3u * sizeof(float), hipMemcpyDeviceToHost, root->ownStream));
+  HIP_TRY(hipStreamSynchronize(root->ownStream));
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->upload_s = root->uploadSeconds;
+    stats->render_s = nowSeconds() - t0;  // whole job: slowest part + gather + resolve + copy back
+  }
+  return PTX_OK;
+}
+
+int ptx_render_counts_multi(ptx_scene* const* scenes, uint32_t count, const ptx_camera* cam, const ptx_params* frame, uint32_t* out,
+                            ptx_stats* stats) {
+  if (!cam || !frame || !out) return fail(PTX_EINVAL, "null argument");
+  const size_t nPixels = (size_t)frame->width * frame->height;
+  const size_t plane = nPixels * sizeof(uint32_t);
+  int rc = multiSetup(scenes, count, plane * count);
+  if (rc) return rc;
+  ptx_scene* root = scenes[0];
+  const double t0 = nowSeconds();
+  for (uint32_t i = 0; i < count; i++) {
+    ptx_scene* s = scenes[i];
+    ptx_params p = *frame;
+    p.part_index = i;  // tile partition: 8x8 tiles with tile % count == i, zeros elsewhere
+    p.part_count = count;
+    FrameConstants fc;
+    if ((rc = makeFrame(s, cam, &p, true, fc))) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    uint32_t* dst = (uint32_t*)root->dGather;
+    if (i != 0) {
+      if ((rc = ensureOut(s, plane))) return rc;
+      dst = (uint32_t*)s->outBuf;
+    }
+    if ((rc = launchCounts(s, fc, dst, s->ownStream, false))) return rc;
+    if (i != 0 && (rc = sendToRoot(root, s, i, dst, plane))) return rc;
+  }
+  HIP_TRY(hipSetDevice(root->device));
+  if ((rc = ensureOut(root, plane))) return rc;
+  sumCountsKernel<<<dim3((uint32_t)((nPixels + 255u) / 256u)), dim3(256), 0, root->ownStream>>>((const uint32_t*)root->dGather, count,
+                                                                                                  (uint32_t)nPixels, (uint32_t*)root->outBuf);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, root->outBuf, plane, hipMemcpyDeviceToHost, root->ownStream));
+  HIP_TRY(hipStreamSynchronize(root->ownStream));
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->upload_s = root->uploadSeconds;
+    stats->render_s = nowSeconds() - t0;
+  }
+  return PTX_OK;
+}
+
 int ptx_measure(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, int heatmap, ptx_stats* stats) {
   FrameConstants fc;
   int rc = makeFrame(s, cam, prm, heatmap != 0, fc);
@@ -969,6 +1122,13 @@ extern "C" int ptx_debug_wave_profile(unsigned long long* out32) {
   if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(ptx::gWaveProfile), sizeof(unsigned long long) * 32) != hipSuccess) return -2;
   unsigned long long zero[32] = {};
   if (hipMemcpyToSymbol(HIP_SYMBOL(ptx::gWaveProfile), zero, sizeof(zero)) != hipSuccess) return -2;
+  return 0;
+}
+#endif
+
+#if defined(PTX_WAVE_PROFILE) && defined(PTX_EXPERIMENT_PHASES)
+extern "C" int ptx_debug_sp_hist(unsigned long long* out128) {
+  if (hipMemcpyFromSymbol(out128, HIP_SYMBOL(ptx::gSpHist), sizeof(unsigned long long) * 128) != hipSuccess) return -2;
   return 0;
 }
 #endif

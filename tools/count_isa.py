@@ -9,7 +9,12 @@ cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ff
        f"{REPO}/path-tracer_amd/csrc/ptx_backend.hip", "-o", f"{tmp}/k.s"] + sys.argv[1:]
 subprocess.check_call(cmd)
 text = open(f"{tmp}/k.s").read()
-m = re.search(r"^_ZN3ptx10pathKernelILi1ELb0ELb" + ("1" if os.environ.get("ISA_WIDE") else "0") + r"E.*?:\n(.*?)s_endpgm", text, re.S | re.M)
+# ISA_KERNEL=radiance: the phase kernel (radiance_kernel.hpp); default: pathKernel, radiance, binary (ISA_WIDE=1: wide)
+if os.environ.get("ISA_KERNEL") == "radiance":
+    pat = r"^_ZN3ptx14radianceKernelILb0EEE.*?:\n(.*?)s_endpgm"
+else:
+    pat = r"^_ZN3ptx10pathKernelILi1ELb0ELb" + ("1" if os.environ.get("ISA_WIDE") else "0") + r"E.*?:\n(.*?)s_endpgm"
+m = re.search(pat, text, re.S | re.M)
 lines = m.group(1).splitlines()
 region = "PRE"
 # issue cost per wave64 instruction per SIMD, measured with tools/ubench_valu2.hip (gpurun_out/ubench_valu2.txt)
@@ -37,15 +42,17 @@ for ln in lines:
         ops.setdefault(region, {}).setdefault(base, 0)
         ops[region][base] += 1
     if region not in counts:
-        counts[region] = {"valu": 0, "salu": 0, "mem": 0, "nop": 0}
+        counts[region] = {"valu": 0, "salu": 0, "mem": 0, "nop": 0, "scratch": 0}
         order.append(region)
     if op == "s_nop":
         counts[region]["nop"] += 1
     counts[region][kind] += 1
-tot = {"valu": 0, "salu": 0, "mem": 0, "nop": 0}
+    if op.startswith("scratch_"):
+        counts[region]["scratch"] += 1
+tot = {"valu": 0, "salu": 0, "mem": 0, "nop": 0, "scratch": 0}
 for r in order:
     c = counts[r]
-    print(f"{r:12s} valu {c['valu']:4d}  salu {c['salu']:4d} (nop {c['nop']:3d})  mem {c['mem']:3d}  valu-cycles {cyc.get(r, 0.0):7.1f}")
+    print(f"{r:12s} valu {c['valu']:4d}  salu {c['salu']:4d} (nop {c['nop']:3d})  mem {c['mem']:3d} (scratch {c['scratch']:2d})  valu-cycles {cyc.get(r, 0.0):7.1f}")
     if os.environ.get("ISA_OPS") and r not in ("PRE", "TRAV_END"):
         print("      " + ", ".join(f"{k}:{v}" for k, v in sorted(ops.get(r, {}).items(), key=lambda kv: -kv[1])))
     if r not in ("PRE", "TRAV_END"):
