@@ -240,7 +240,9 @@ int makeFrame(const ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, 
   fc.sppBase = fc.spp / streams;
   fc.sppExtra = fc.spp % streams;
   fc.seedBase = 1023u;
-  if (prm->seed_mode == PTX_SEED_STREAM) fc.seedBase += prm->part_index * streams * 0x9E3779B9u;
+  // stream id of this call's k-th stream = part_index * sub_streams + k with the REQUESTED sub_streams: a part whose
+  // share of the samples is smaller than that runs fewer streams, and its ids must not slide into its neighbour's
+  if (prm->seed_mode == PTX_SEED_STREAM) fc.seedBase += prm->part_index * (prm->sub_streams > 1u && !heatmap ? prm->sub_streams : 1u) * 0x9E3779B9u;
   else if (prm->seed_mode != PTX_SEED_REFERENCE_GPU) return fail(PTX_EINVAL, "unknown seed_mode");
   fc.partIndex = prm->part_index;
   fc.partCount = prm->part_count;

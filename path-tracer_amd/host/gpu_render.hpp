@@ -9,6 +9,16 @@
 
 namespace pt {
 
+// What the reference's argument list has no place for (set once before the render calls; defaults =
+// the reference's behaviour: one GPU, the reference's seeding).
+struct GpuOptions {
+  uint32_t numGpus = 1;     // -g: devices 0 .. numGpus-1 driven from this process (ptx_render_multi); > 1 implies
+                            //     PTX_SEED_STREAM (one RNG stream set per GPU; part 0 is the reference's seeding)
+  uint32_t subStreams = 0;  // -r: RNG streams per pixel and GPU (ptx_params.sub_streams); > 1 implies PTX_SEED_STREAM
+  bool sameDevice = false;  // PT_MULTI_SAME_DEVICE=1: every part on device 0 (rehearsal of -g on a one-GPU machine)
+};
+void setGpuOptions(const GpuOptions& options);
+
 void renderGPU(const Scene& scene, const std::vector<std::shared_ptr<Geometry>>& geometryPool,
                const std::vector<std::shared_ptr<Material>>& materialPool, const Camera& camera, Image& image,
                const Image& environment, const uint samples, const int maxBounces, const bool renderBVH);

@@ -31,7 +31,9 @@ int main(int argc, char** argv) {
   SampleScene sampleScene{THREE_STL};
 
   int opt;
-  while ((opt = getopt(argc, argv, " w:h:s:b:t:p:ad:")) != -1) {
+  GpuOptions gpuOptions;  // -g / -r: not in the reference
+  if (const char* e = getenv("PT_MULTI_SAME_DEVICE")) gpuOptions.sameDevice = e[0] == '1';
+  while ((opt = getopt(argc, argv, " w:h:s:b:t:p:ad:g:r:")) != -1) {
     switch (opt) {
       case 'w': width = atoi(optarg); continue;
       case 'h': height = atoi(optarg); continue;
@@ -41,9 +43,13 @@ int main(int argc, char** argv) {
       case 'p': sampleScene = static_cast<SampleScene>(atoi(optarg)); continue;
       case 'a': renderBVH = true; continue;
       case 'd': gpuRender = atoi(optarg) == 0; continue;
+      case 'g': gpuOptions.numGpus = (uint32_t)std::max(1, atoi(optarg)); continue;
+      case 'r': gpuOptions.subStreams = (uint32_t)std::max(0, atoi(optarg)); continue;
       default:
         printf("Options\n-d\t0: GPU (default), 1: CPU (not in this binary: see oracle/)\n-w\t<width>\n-h\t<height>\n-s\t<samples>\n"
-               "-t\t<threads>\n-b\t<bounces>\n-p\t<0|1|2>\tpreset scene\n-a\trender BVH heat map (only main ray, single sample, no jitter)\n");
+               "-t\t<threads>\n-b\t<bounces>\n-p\t<0|1|2>\tpreset scene\n-a\trender BVH heat map (only main ray, single sample, no jitter)\n"
+               "-g\t<gpus>\tGPUs to split the frame over (samples for radiance, 8x8 tiles for -a); default 1\n"
+               "-r\t<streams>\tRNG streams per pixel and GPU (faster on large GPUs; default: the reference's one stream per pixel)\n");
         return EXIT_SUCCESS;
     }
     break;
@@ -59,7 +65,9 @@ int main(int argc, char** argv) {
     return EXIT_FAILURE;
   }
   numThreads = 1u;
-  printf("Rendering using HIP (gfx950)\n");
+  setGpuOptions(gpuOptions);
+  if (gpuOptions.numGpus > 1) printf("Rendering using HIP (gfx950) on %u GPUs\n", gpuOptions.numGpus);
+  else printf("Rendering using HIP (gfx950)\n");
   printf("\nDimensions: [%u, %u]\tSamples: %u\tBounces: %u\tThreads: %u\n\n", width, height, samples, bounces, numThreads);
 
   Image image{width, height};
@@ -91,7 +99,7 @@ int main(int argc, char** argv) {
   // runs on the device by default; PT_HOST_OUTPUT=1 takes the reference-shaped route through renderGPU
   // and the host functions (same bytes in output.bmp, 4x the PCIe traffic).
   const char* hostOutput = getenv("PT_HOST_OUTPUT");
-  if (hostOutput && hostOutput[0] == '1') {
+  if ((hostOutput && hostOutput[0] == '1') || gpuOptions.numGpus > 1) {  // the multi-GPU entry points return floats / counts
     renderGPU(scene, geometryPool, materialPool, camera, image, environment, samples, (int)bounces, renderBVH);
     if (renderBVH) {  // main.cpp:363-374
       std::vector<uint32_t> counts(image.data.size());

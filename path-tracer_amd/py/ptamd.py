@@ -249,7 +249,7 @@ BACKEND_SYMBOLS = [
     "ptx_device_count", "ptx_create", "ptx_render_counts", "ptx_render", "ptx_accumulate_device",
     "ptx_resolve_device", "ptx_counts_device", "ptx_measure", "ptx_last_kernel_seconds", "ptx_destroy",
     "ptx_last_error", "ptx_version", "ptx_check_wide_layout", "ptx_selftest_reciprocal", "ptx_render_counts_bgr8",
-    "ptx_render_bgr8", "ptx_accumulate_device_noalloc",
+    "ptx_render_bgr8", "ptx_accumulate_device_noalloc", "ptx_render_multi", "ptx_render_counts_multi",
 ]
 NOALLOC_SCRATCH_BYTES = 128 << 20  # PTX_NOALLOC_SCRATCH_BYTES
 
@@ -270,6 +270,8 @@ def backend_lib():
         lib.ptx_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.POINTER(Stats)]
         lib.ptx_accumulate_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, vp]
         lib.ptx_accumulate_device_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, vp]
+        lib.ptx_render_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(Camera), C.POINTER(Params), vp, C.POINTER(Stats)]
+        lib.ptx_render_counts_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(Camera), C.POINTER(Params), vp, C.POINTER(Stats)]
         lib.ptx_resolve_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp]
         lib.ptx_counts_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, vp]
         lib.ptx_measure.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), C.c_int, C.POINTER(Stats)]
@@ -373,3 +375,25 @@ class DeviceScene:
         s = C.c_double()
         _check(backend_lib().ptx_last_kernel_seconds(self._h, C.byref(s)), "ptx_last_kernel_seconds")
         return s.value
+
+
+def _handles(dscenes):
+    arr = (C.c_void_p * len(dscenes))(*[d._h for d in dscenes])
+    return arr
+
+
+def render_multi(dscenes, camera, params):
+    """ptx_render_multi: one frame over the devices of `dscenes` (one DeviceScene per device)."""
+    out = np.empty((params.height, params.width, 3), dtype=np.float32)
+    st = Stats()
+    _check(backend_lib().ptx_render_multi(_handles(dscenes), len(dscenes), C.byref(camera), C.byref(params), out.ctypes.data,
+                                          C.byref(st)), "ptx_render_multi")
+    return out, st
+
+
+def render_counts_multi(dscenes, camera, params):
+    out = np.empty((params.height, params.width), dtype=np.uint32)
+    st = Stats()
+    _check(backend_lib().ptx_render_counts_multi(_handles(dscenes), len(dscenes), C.byref(camera), C.byref(params),
+                                                 out.ctypes.data, C.byref(st)), "ptx_render_counts_multi")
+    return out, st
