@@ -19,7 +19,8 @@
 //   0x00000000..0x7FFFFFFF  internal node: index of its NodePair
 //   0x80000000..0xBFFFFFFF  BLAS leaf:  bits 29..23 = triangle count - 1, bits 22..0 = first triangle (absolute)
 //   0xC0000000..0xFFFFFFFC  TLAS leaf:  bits 29..24 = instance count - 1, bits 23..0 = first instance
-//   0xFFFFFFFD / E / F      lane idle / traversal done / leave the current instance
+//   0xFFFFFFFD / E          lane idle / traversal done (the bottom-of-stack marker)
+//   (0xFFFFFFFF: instance-exit marker of the experimental phase kernel only)
 #pragma once
 
 #include <stdint.h>
@@ -106,6 +107,7 @@ struct DeviceScene {
   const float4* environment;
   uint32_t tlasRootRef;
   uint32_t tlasRootRefWide;  // the TLAS root in the wide layout
+  uint32_t tlasNodeEnd[2];   // internal-node references below this belong to the TLAS ([0] NodePair, [1] WideNode index)
   uint32_t envWidth, envHeight;
 };
 
@@ -127,6 +129,8 @@ struct FrameConstants {
   uint32_t tilesX, tilesY;
   uint32_t subStreams;          // RNG streams per pixel in this launch (>= 1), each a separate work item
   uint32_t sppBase, sppExtra;   // stream k renders sppBase + (k < sppExtra) samples
+  uint32_t widthMul, widthShift;  // n / width for n < 2^24: umulhi(n << 8, widthMul) >> widthShift
+  double invSubStreams;           // 1.0 / subStreams
 };
 
 struct DeviceStats {  // accumulated with atomics by the instrumented kernel variants

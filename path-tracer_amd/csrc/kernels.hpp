@@ -10,8 +10,8 @@
 //                       radiance    : up to four quantised child boxes of one 64-byte WideNode
 //                                     (wide_bvh.hpp), sort, push up to three
 //      BLAS leaf      : one Moeller-Trumbore test
-//      TLAS leaf      : enter the next instance (ray -> object space, marker pushed)
-//      kRefInstExit   : leave the instance (ray -> world space)
+//      TLAS leaf      : enter the next instance (ray -> object space); the instance is left, at no step
+//                       of its own, by the pop that reaches a TLAS-level entry of the stack
 //      kRefDone       : traversal finished, wait for the shading phase
 //      kRefIdle       : no work left
 //
@@ -145,6 +145,13 @@ __device__ __forceinline__ void workPixel(const FrameConstants& fc, uint32_t w, 
   y = band * 8u + (r - cx * rows);
 }
 
+// n / fc.width for n < 2^24 (a pixel index) without the compiler's division sequence, whose hoisted per-lane
+// reciprocal would occupy a VGPR for the whole kernel: multiplier and shift come from the host (makeFrame),
+// exact for every 24-bit numerator (M = ceil(2^(24+s) / width), s = ceil(log2 width)).
+__device__ __forceinline__ uint32_t divByWidth(const FrameConstants& fc, uint32_t n) {
+  return __umulhi(n << 8, fc.widthMul) >> fc.widthShift;
+}
+
 template <int MODE, bool STATS, bool WIDE>
 __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(DeviceScene sc, FrameConstants fc, uint32_t* workCounter,
                                                             void* __restrict__ outRaw, DeviceStats* stats,
@@ -163,15 +170,14 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
 
   // ---- lane state ----
   uint32_t ref = kRefDone;   // what the lane does next (see the table above)
-  bool pending = false;      // a traced ray's result waits for the shading phase
-  bool havePixel = false;
+  bool havePixel = false;    // the lane owns a work item; at the shading phase: its ray's result is waiting
   bool zeroDir = false;      // a component of the current ray's direction is exactly 0 (0*inf possible)
   bool wZeroDir = false;     // the same for the world-space ray (restored when an instance is left)
   uint32_t pix = 0;     // pixel index (bits 0..23) | RNG stream of this item (bits 24..31)
   uint32_t sample = 0;  // samples (rays, for the one-ray modes) this item still has to do; 0 = pull the next item
   uint32_t bounce = 0, rng = 0, count = 0;
   uint32_t tlasLeaf = 0, curInst = 0;
-  float tBeforeInst = FLT_MAX;
+  bool inInst = false;  // the current ray is in an instance's object space
   vec3 sum(0.0f), col(1.0f);
   vec3 wo(0.0f), wd(0.0f, 0.0f, -1.0f), winv(0.0f);  // world-space ray
   vec3 o(0.0f), d(0.0f, 0.0f, -1.0f), inv(0.0f);     // current ray (world or object space)
@@ -201,8 +207,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       PTX_PROF(1, waiting);
       if (waiting) {
         bool pathEnded = true;
-        if (pending) {
-          pending = false;
+        if (havePixel) {
           if (STATS) {
             nRays++;
             nBoxHits += count;
@@ -244,9 +249,20 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
               havePixel = false;
               break;
             }
-            const uint32_t k = fc.subStreams > 1u ? w / nPixels : 0u;
+            // item -> (pixel slot, stream): the streams of a pixel are neighbours; slots walk the image in 8x8 blocks.
+            // (Handing the pixels out most expensive first -- priced by the heat-map kernel, counting sort over 256
+            // cost classes -- was built and measured: 474 -> 470 ms with the reference's seeding, 352.6 -> 351.7 ms
+            // with 25 streams, less than the pre-pass costs.  The frame's tail is not late starts of expensive
+            // pixels but the length of the single longest chain; profiles/r02/cost_order_ab.txt.)
+            uint32_t slot = w, k = 0u;
+            if (fc.subStreams > 1u) {
+              slot = (uint32_t)((double)w * fc.invSubStreams);  // w < 2^32, exact up to one unit either way
+              k = w - slot * fc.subStreams;
+              if ((int32_t)k < 0) { slot--; k += fc.subStreams; }
+              else if (k >= fc.subStreams) { slot++; k -= fc.subStreams; }
+            }
             uint32_t x, y;
-            workPixel(fc, w - k * nPixels, x, y);
+            workPixel(fc, slot, x, y);
             const uint32_t p = y * fc.width + x;
             pix = p | (k << 24);
             sum = vec3(0.0f);
@@ -270,7 +286,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
             PTX_MARK("S_CAMERA");
             // ---- next camera ray: gpuRender.cu:132-143 ----
             const uint32_t p = pix & 0x00FFFFFFu;
-            const uint32_t py = p / fc.width, px = p - py * fc.width;
+            const uint32_t py = divByWidth(fc, p), px = p - py * fc.width;
             float fx = (float)px, fy = (float)py;
             if (MODE == kModeRadiance && fc.jitter) {
               const vec2 xi = pt::getRandomVec2(rng);
@@ -292,10 +308,10 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
           hit.t = FLT_MAX; hit.u = 0.0f; hit.v = 0.0f; hit.tri = 0xFFFFFFFFu; hit.inst = 0xFFFFFFFFu;
           count = 0u;
           tlasLeaf = 0u;
+          inInst = false;
           stk.lds[0] = kRefDone;  // slot 0: bottom-of-stack marker
           sp = 1u;
           ref = WIDE ? sc.tlasRootRefWide : sc.tlasRootRef;
-          pending = true;
         } else {
           ref = kRefIdle;
         }
@@ -308,8 +324,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
     for (int it = 0; it < PTX_INNER_ITERS; it++) {
       PTX_MARK("TRAV_BEGIN");
       const bool isNode = (int32_t)ref >= 0;
-      const bool isSpecial = ref >= kRefIdle;  // idle / done / instance exit
-      bool isExit = ref == kRefInstExit;
+      const bool isSpecial = ref >= kRefIdle;  // idle / done
       const bool isTri = (ref >> 30) == 2u;
       bool isEnter = (ref >> 30) == 3u && !isSpecial;
       if (PTX_ENTER_THRESHOLD > 1 && MODE == kModeRadiance) {
@@ -321,12 +336,9 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       if (PTX_RARE_PERIOD > 1) {
         // instance entry / exit bodies run on every PTX_RARE_PERIOD-th iteration only (a lane waits at
         // most PTX_RARE_PERIOD - 1 iterations for them), unless no lane has anything else to do
-        if ((loopCount % PTX_RARE_PERIOD) != 0u && __any(isNode || isTri)) {
-          isEnter = false;
-          isExit = false;
-        }
+        if ((loopCount % PTX_RARE_PERIOD) != 0u && __any(isNode || isTri)) isEnter = false;
       }
-      const bool steps = isNode || isTri || isEnter || isExit;
+      const bool steps = isNode || isTri || isEnter;
       const uint32_t first = ref & (isTri ? 0x007FFFFFu : 0x00FFFFFFu);
       const uint32_t nPrim = (isTri ? ((ref >> 23) & 0x7Fu) : ((ref >> 24) & 0x3Fu)) + 1u;
 
@@ -360,35 +372,21 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       PTX_STAMP(2);  // waiting for the record and the stack top
 
       PTX_PROF(2, steps);
-      if (__any(isExit)) PTX_PROF(3, isExit);
       if (__any(isEnter)) PTX_PROF(4, isEnter);
       if (__any(isTri)) PTX_PROF(5, isTri);
       if (__any(isNode)) PTX_PROF(6, isNode);
       if (__any(isNode) && __any(zeroDir)) PTX_PROF(7, isNode);
-      PTX_MARK("EXIT");
-      if (isExit) {
-        // GPUMesh::intersect returns (ray.t = transformedRay.t); intersectTLAS keeps the instance if it
-        // lowered t (intersection.hpp:184-189).
-        if (hit.t < tBeforeInst) hit.inst = curInst;
-        o = wo; d = wd; inv = winv;
-        zeroDir = wZeroDir;
-        doPop = tlasLeaf == 0u;
-        newRef = doPop ? top : tlasLeaf;
-        tlasLeaf = 0u;
-      }
       PTX_STAMP(3);
       PTX_MARK("ENTER");
       if (isEnter) {
         // TLAS leaf: enter its first instance, keep the rest of the leaf (gpuFunctions.hpp:32-41).
         tlasLeaf = (nPrim > 1u) ? makeTlasLeafRef(first + 1u, nPrim - 1u) : 0u;
         curInst = first;
+        inInst = true;
         o = xformRows(r0, r1, r2, wo, 1.0f);
         d = xformRows(r0, r1, r2, wd, 0.0f);  // not normalised: t stays world-space
         reciprocalDir(d, inv, zeroDir);
-        tBeforeInst = hit.t;
         if (STATS) nInstEntries++;
-        pushVal = kRefInstExit;
-        doPush = true;
         newRef = __float_as_uint(WIDE ? r3.y : r3.x);  // InstXform::rootRef / wideRootRef
       }
       PTX_STAMP(4);
@@ -400,7 +398,9 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
         float u = 0.0f, v = 0.0f;
         const float dist = triangleTest(o, d, tri, u, v);
         if (dist < hit.t) {
-          hit.t = dist; hit.u = u; hit.v = v; hit.tri = first;
+          // the instance is recorded with the hit: intersectTLAS keeps the instance whose BLAS lowered t
+          // (GPUMesh::intersect returns ray.t = transformedRay.t, intersection.hpp:184-189)
+          hit.t = dist; hit.u = u; hit.v = v; hit.tri = first; hit.inst = curInst;
         }
         if (STATS) nTriTests++;
         doPop = nPrim == 1u;
@@ -458,6 +458,26 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
 
       PTX_STAMP(6);
       PTX_MARK("MERGE");
+      {
+        // Leaving an instance costs no step of its own and no marker on the stack: a pop that would hand out
+        // an entry of the TLAS level (a TLAS node or leaf, or the bottom marker) while the ray is in object
+        // space means the BLAS is finished (the `return` of intersectBVH, intersection.hpp:99-163): the ray
+        // goes back to world space and carries on with the rest of its TLAS leaf, or with that entry.
+        const bool leaving = doPop && inInst && (top < sc.tlasNodeEnd[WIDE ? 1 : 0] || top >= kTlasLeafFlag);
+        if (__any(leaving)) {
+          PTX_PROF(3, leaving);
+          if (leaving) {
+            o = wo; d = wd; inv = winv;
+            zeroDir = wZeroDir;
+            inInst = false;
+            if (tlasLeaf != 0u) {
+              newRef = tlasLeaf;
+              doPop = false;
+              tlasLeaf = 0u;
+            }
+          }
+        }
+      }
       if (WIDE) {
         if (steps) {
           // the one deferred reference of the other bodies is "child 1 of 1"

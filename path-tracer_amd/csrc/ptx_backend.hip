@@ -239,6 +239,13 @@ int makeFrame(const ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, 
   fc.subStreams = streams;
   fc.sppBase = fc.spp / streams;
   fc.sppExtra = fc.spp % streams;
+  fc.invSubStreams = 1.0 / (double)streams;
+  {
+    uint32_t sh = 0;
+    while ((1u << sh) < prm->width) sh++;  // width <= 2^24
+    fc.widthShift = sh;
+    fc.widthMul = (uint32_t)((((uint64_t)1 << (24 + sh)) + prm->width - 1u) / prm->width);  // <= 2^25
+  }
   fc.seedBase = 1023u;
   // stream id of this call's k-th stream = part_index * sub_streams + k with the REQUESTED sub_streams: a part whose
   // share of the samples is smaller than that runs fewer streams, and its ids must not slide into its neighbour's
@@ -489,6 +496,7 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
   TreeInfo tlas;
   int rc = convertTree(d->tlas_nodes, d->tlas_node_count, 0u, d->instance_count, true, pairs, tlas);
   if (rc) return rc;
+  const uint32_t tlasPairEnd = (uint32_t)pairs.size();
 
   std::vector<TreeInfo> blas(d->geometry_count);
   std::vector<GeomShade> geomShade(d->geometry_count);
@@ -514,10 +522,11 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
   std::vector<WideNode> wideNodes;
   WideInfo tlasWide;
   std::vector<WideInfo> blasWide(d->geometry_count);
-  uint32_t blasWideDepth = 0;
+  uint32_t blasWideDepth = 0, tlasWideEnd = 0;
   {
     std::string err = buildWideTree(d->tlas_nodes, d->tlas_node_count,
                                     [&](const ptx_bvh_node& nd) { return makeTlasLeafRef(nd.left_first, nd.count); }, wideNodes, tlasWide);
+    tlasWideEnd = (uint32_t)wideNodes.size();
     for (uint32_t g = 0; g < d->geometry_count && err.empty(); g++) {
       const ptx_geometry& G = d->geometries[g];
       err = buildWideTree(d->blas_nodes + G.node_offset, G.node_count,
@@ -669,6 +678,8 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
   D.environment = (const float4*)(base + oEnv);
   D.tlasRootRef = tlas.rootRef;
   D.tlasRootRefWide = tlasWide.rootRef;
+  D.tlasNodeEnd[0] = tlasPairEnd;
+  D.tlasNodeEnd[1] = tlasWideEnd;
   s->wideStackBound = wideStackBound;
   D.envWidth = d->env_width;
   D.envHeight = d->env_height;

@@ -108,17 +108,19 @@ __device__ __forceinline__ void shadeHit(const DeviceScene& sc, const Hit& hit, 
 
   vec3 localCol, sampleDir;
   const vec2 Xi = pt::getRandomVec2(rng);
-  if (metalness == 0.0f) {
-    // Lambert: cosine-weighted direction, weight = albedo (gpuRender.cu:56-69, brdf.hpp:32-41)
-    const float cosTheta = sqrtf(1.0f - Xi.x);
-    sampleDir = rotateToNormal(tangentSample(cosTheta, Xi.y), N);
+  // Both branches of gpuRender.cu:56-105 turn (cosTheta, Xi.y) into a direction around N with the same code
+  // (brdf.hpp:32-41 / :45-54): a wave that holds diffuse and metallic hits runs it once, not twice.
+  const bool diffuse = metalness == 0.0f;
+  const float a = roughness;
+  const float cosTheta = diffuse ? sqrtf(1.0f - Xi.x) : sqrtf((1.0f - Xi.x) / (1.0f + (a * a - 1.0f) * Xi.x));
+  const vec3 H = rotateToNormal(tangentSample(cosTheta, Xi.y), N);
+  if (diffuse) {
+    // Lambert: cosine-weighted direction, weight = albedo (gpuRender.cu:56-69)
+    sampleDir = H;
     localCol = albedo;
   } else {
-    // GGX half vector, reflect, weight = F*G*VdotH / (NdotV*NdotH) (gpuRender.cu:71-105, brdf.hpp:45-74)
+    // GGX half vector, reflect, weight = F*G*VdotH / (NdotV*NdotH) (gpuRender.cu:71-105, brdf.hpp:62-74)
     const vec3 F0 = pt::mix(f4xyz(mat.f0), albedo, metalness);
-    const float a = roughness;
-    const float cosTheta = sqrtf((1.0f - Xi.x) / (1.0f + (a * a - 1.0f) * Xi.x));
-    const vec3 H = rotateToNormal(tangentSample(cosTheta, Xi.y), N);
     sampleDir = pt::normalize(pt::reflect(-V, H));
     const float NdotL = dotClamped(N, sampleDir);
     const float NdotV = dotClamped(N, V);

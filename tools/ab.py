@@ -24,6 +24,12 @@ for i in range(%(iters)d):
 pc = ptamd.make_params(1500, 800)
 c, stc = d.render_counts(s.camera, pc)
 out = {"render_ms": [round(t*1e3, 2) for t in ts], "counts_ms": round(stc.render_s*1e3, 3), "counts_sum": int(c.sum()), "counts_max": int(c.max()), "img_mean": float(img.mean())}
+import zlib
+out["img_crc"] = zlib.crc32(np.ascontiguousarray(img).tobytes())
+if %(measure)d:
+    m = d.measure(s.camera, p)
+    out.update(rays=m.rays, S=m.node_steps, T=m.tri_tests, I=m.inst_entries)
+    np.save(os.path.join(%(repo)r, "gpurun_out", "ab_img_" + os.path.basename(os.environ["PTX_BACKEND_LIB"]) + ".npy"), img)
 if check:
     import oracle_binding as ob
     ref, _ = ob.render_counts(s, pc)
@@ -39,6 +45,7 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--scene", type=int, default=1)
     ap.add_argument("--check", type=int, default=1)
+    ap.add_argument("--measure", type=int, default=0, help="instrumented launch (step counts) and the image saved under gpurun_out/")
     ap.add_argument("names", nargs="+")
     a = ap.parse_args()
     res = {n: [] for n in a.names}
@@ -50,7 +57,7 @@ def main():
             for kv in parts[1:]:
                 k, v = kv.split("=", 1)
                 env[k] = v
-            code = CHILD % {"repo": REPO, "scene": a.scene, "spp": a.spp, "check": a.check if r == 0 else 0, "iters": a.iters}
+            code = CHILD % {"repo": REPO, "scene": a.scene, "spp": a.spp, "check": a.check if r == 0 else 0, "iters": a.iters, "measure": a.measure if r == 0 else 0}
             out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
             if out.returncode != 0:
                 print(n, "FAILED", out.stderr[-800:], flush=True)
