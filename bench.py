@@ -22,10 +22,22 @@ config.reference_seeding.
 
 A ray is one call of Scene::intersect (gpuRender.cu:32): rays per step are counted exactly by an
 instrumented launch of the same kernel (paths are deterministic in pixel and seed), outside the
-timed region.  roofline.achieved = algorithmic bytes per launch / kernel time measured with HIP
-events on the launch stream; algorithmic bytes = 64*S + 36*T + 144*I + 12*hits + 12*misses + 12*W*H
-(reference-layout bytes per internal-node step, triangle test, instance entry,
-face normal, environment texel, output pixel).
+timed region.
+
+roofline (the path kernel; its time is measured live with HIP events on the launch stream):
+  frac / achieved   bytes the L2 requested from the memory side per launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE,
+                    the gfx950 correction of MI355X_MICROARCH.md; per-ray figure of profiles/traffic.json x this
+                    launch's rays) / kernel time, against the 8 TB/s HBM peak.  Infinity-Cache hits are included
+                    in the counter and the 98-MB scene lives there, so this is an upper bound of the HBM share.
+  l1_level          SURVEY.md section 8d's algorithmic bytes (64*S + 36*T + 144*I + 12*hits + 12*misses + 12*W*H:
+                    reference-layout bytes per node step, triangle test, instance entry, face normal, environment
+                    texel, output pixel) / kernel time.  These are bytes every step needs at the register file;
+                    they are served by L1 / L2 / Infinity Cache re-reads and may exceed the HBM peak.
+  memory_path       16-byte lane-accesses (4 per node step and instance entry, 3 per triangle test) against the
+                    rate a pure gather of the same shape sustains (tools/ubench_gather2.hip).
+  valu              what binds the kernel: VALU wave-instructions per launch (SQ_INSTS_VALU per ray x rays)
+                    against 1024 SIMDs x clock / 2.5 cycles per instruction (tools/ubench_valu2.hip), and the
+                    share of the 64 lanes that were active in them.
 
 cpu_baseline (rank 0, N=1 only) times the CPU oracle -- this repository's restatement of the
 reference's `-d 1` path -- on a bounded sample of the same workload.
@@ -46,6 +58,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # its width (tools/ubench_gather2.hip, gpurun_out/ubench_gather3.txt: 180.8 cycles for 4 loads, L1
 # resident), i.e. 64 / 45.2 lane-accesses per cycle per CU.
 LANE_ACCESS_PEAK_G = 256 * (64 / 45.2) * 2.4  # G lane-accesses/s for 256 CUs at 2.4 GHz
+# VALU issue: one plain wave64 instruction per 2.5 cycles and SIMD (profiles/r01/ubench_valu2.txt: 2.4-2.7 for
+# fma / mul / add / logic at 4-8 waves per SIMD; min / max / compare / select classes issue slower on their own)
+VALU_PEAK_G = 256 * 4 * 2.4 / 2.5  # G wave-instructions/s for 1024 SIMDs at 2.4 GHz
 
 
 def algorithmic_bytes(st, width, height, hit_bytes=12):
@@ -211,13 +226,21 @@ def main():
         avg_kernel = sum(kernel_s) / len(kernel_s)
         alg = algorithmic_bytes(stats, WIDTH, HEIGHT)
         lane_acc = 4 * stats.node_steps + 3 * stats.tri_tests + 4 * stats.inst_entries
-        traffic = None
+        # counters of the committed rocprofv3 --pmc passes (profiles/traffic.json, made by tools/make_traffic.py from
+        # profiles/r02): per-ray figures of this kernel on this scene / resolution / bounce count, scaled to this
+        # launch's exact ray count (the passes ran the 100-spp frame; a rank of an N-GPU job traces fewer samples)
+        traffic = valu = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 --pmc passes
+        if os.path.exists(tpath):
             with open(tpath) as f:
                 t = json.load(f)
-            if t.get("workload") == f"scene{SCENE}_{WIDTH}x{HEIGHT}_{spp}spp_{BOUNCES}b":
-                traffic = t.get("hbm_bytes_per_launch")
+            if t.get("workload", "").startswith(f"scene{SCENE}_{WIDTH}x{HEIGHT}_") and t.get("workload", "").endswith(f"_{BOUNCES}b"):
+                traffic = t["hbm_bytes_per_ray"] * stats.rays
+                insts = t["valu_insts_per_ray"] * stats.rays
+                valu = {"bound": "VALU issue (wave-instructions)", "insts": insts, "per_ray": t["valu_insts_per_ray"],
+                        "achieved": insts / avg_kernel / 1e9, "peak": VALU_PEAK_G, "unit": "G wave-instructions/s",
+                        "frac": insts / avg_kernel / 1e9 / VALU_PEAK_G, "lane_utilisation": t.get("valu_lane_utilisation"),
+                        "source": "profiles/traffic.json (" + t.get("source", "") + ")"}
         line = {
             "metric": "Mrays/s at 1500x800, 100spp, 6 bounces, Scene 1",
             "value": total_rays * args.steps / elapsed / 1e6,
@@ -240,10 +263,15 @@ def main():
                 "rays_per_step": total_rays, "paths_per_step": WIDTH * HEIGHT * frame_spp,
             },
             "roofline": {
-                "bound": "hbm", "achieved": alg / avg_kernel / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": alg / avg_kernel / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "ptx::pathKernel<1, false, true>", "kernel_ms": avg_kernel * 1e3, "algorithmic_bytes": alg,
+                "bound": "hbm", "achieved": traffic / avg_kernel / 1e9 if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": traffic / avg_kernel / 1e9 / HBM_PEAK_GBS if traffic else None, "traffic": traffic,
+                "traffic_is": "bytes requested by the L2 from the memory side (FETCH_SIZE x 2 + WRITE_SIZE), Infinity-Cache hits included",
+                "binding": "valu",
+                "kernel": "ptx::pathKernel<1, false, true>", "kernel_ms": avg_kernel * 1e3,
+                "l1_level": {"algorithmic_bytes": alg, "achieved": alg / avg_kernel / 1e9, "unit": "GB/s",
+                             "note": "bytes the steps consume at the register file; re-served from L1 / L2 / Infinity Cache"},
                 "node_steps": stats.node_steps, "tri_tests": stats.tri_tests, "inst_entries": stats.inst_entries,
+                "valu": valu,
                 # the kernel issues 4 16-byte lane-accesses per node step / instance entry and 3 per triangle test
                 "memory_path": {
                     "bound": "vector memory path (lane-accesses: load instructions x active lanes)",

@@ -26,7 +26,11 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert "traffic" in r and r["memory_path"]["frac"] > 0
+    # a fraction of the HBM peak made of measured memory-side bytes (profiles/traffic.json), not of L1-level bytes
+    assert 0.0 < r["frac"] <= 1.0 and r["traffic"] > 0 and abs(r["achieved"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["l1_level"]["algorithmic_bytes"] > r["traffic"] and r["memory_path"]["frac"] > 0
+    v = r["valu"]
+    assert 0.0 < v["frac"] <= 1.0 and 0.0 < v["lane_utilisation"] <= 1.0 and abs(v["insts"] - v["per_ray"] * j["config"]["rays_per_step"]) < 1.0
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     # value = rays of the timed steps / wall time

@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -u tools/ab.py --spp 100 --rounds 2 --iters 2 --check 1 --measure 1 base:AB_STREAMS=25 base:AB_STREAMS=25:PTX_COST_ORDER=0 base:AB_STREAMS=0 base:AB_STREAMS=0:PTX_COST_ORDER=0 base:AB_STREAMS=10 base:AB_STREAMS=5 > gpurun_out/r2k_ab.txt 2>&1; rc=$?; echo rc=$rc; cut -c1-420 gpurun_out/r2k_ab.txt
+timeout -k 10 300 python -u -m pytest tests/test_gpu_bench_contract.py -x -q --timeout 280 --timeout-method thread > gpurun_out/r2m_contract.log 2>&1; echo rc=$?; tail -5 gpurun_out/r2m_contract.log
+timeout -k 10 300 python -u bench.py --steps 5 --warmup 1 > gpurun_out/r2m_bench.log 2>&1; echo rc=$?; tail -1 gpurun_out/r2m_bench.log

@@ -37,5 +37,10 @@ for case, k in known.items():
         e["factor"] = k["known_bytes"] / (c["FETCH_SIZE"] * 1024)
     if c.get("TCC_EA0_RDREQ_sum"):
         e["known_bytes_per_rdreq"] = k["known_bytes"] / c["TCC_EA0_RDREQ_sum"]
+    if c.get("TCC_EA0_RDREQ_128B_sum") is not None:
+        n = c["TCC_EA0_RDREQ_128B_sum"] + c.get("TCC_EA0_RDREQ_64B_sum", 0.0) + c.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+        e["requests_128B_share"] = c["TCC_EA0_RDREQ_128B_sum"] / n if n else None
+        e["moved_bytes"] = 128.0 * c["TCC_EA0_RDREQ_128B_sum"] + 64.0 * c.get("TCC_EA0_RDREQ_64B_sum", 0.0) + 32.0 * c.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+        e["moved_GBps"] = e["moved_bytes"] / (k["ms"] * 1e-3) / 1e9
     out[case] = e
 print(json.dumps(out, indent=1))
