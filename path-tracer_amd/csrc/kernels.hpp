@@ -111,24 +111,26 @@ struct StackMem {
   uint32_t* overflow;  // &overflowBase[global thread]
   uint32_t stride;     // total threads of the launch
 };
+template <uint32_t CAP = kLdsStack>  // entries in LDS
 __device__ __forceinline__ uint32_t stackRead(const StackMem& m, uint32_t slot, bool deep) {
   uint32_t v;
   if (!deep) {
     v = m.lds[slot * kBlockThreads];
   } else {
     // both loads, then a value select: a pointer select would become a (slow, doubly counted) flat load
-    const uint32_t a = m.lds[(slot < kLdsStack ? slot : kLdsStack - 1u) * kBlockThreads];
-    const uint32_t b = m.overflow[(size_t)(slot < kLdsStack ? 0u : slot - kLdsStack) * m.stride];
-    v = slot < kLdsStack ? a : b;
+    const uint32_t a = m.lds[(slot < CAP ? slot : CAP - 1u) * kBlockThreads];
+    const uint32_t b = m.overflow[(size_t)(slot < CAP ? 0u : slot - CAP) * m.stride];
+    v = slot < CAP ? a : b;
   }
   return v;
 }
+template <uint32_t CAP = kLdsStack>
 __device__ __forceinline__ void stackWrite(const StackMem& m, uint32_t slot, uint32_t val, bool deep) {
   if (!deep) {
     m.lds[slot * kBlockThreads] = val;
   } else {
-    if (slot < kLdsStack) m.lds[slot * kBlockThreads] = val;
-    else m.overflow[(size_t)(slot - kLdsStack) * m.stride] = val;
+    if (slot < CAP) m.lds[slot * kBlockThreads] = val;
+    else m.overflow[(size_t)(slot - CAP) * m.stride] = val;
   }
 }
 

@@ -19,6 +19,9 @@
 #ifdef PTX_EXPERIMENT_PHASES  // DESIGN.md section 3, "phase kernel": measured slower, kept for A/B builds only
 #include "radiance_kernel.hpp"
 #endif
+#ifdef PTX_EXPERIMENT_EXCHANGE  // DESIGN.md section 3, "block exchange": measured slower, kept for A/B builds only
+#include "exchange_kernel.hpp"
+#endif
 #include "wide_bvh.hpp"
 
 using namespace ptx;
@@ -424,6 +427,10 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
   // experimental builds: the phase kernel (radiance_kernel.hpp) unless PTX_RAD_LEGACY=1
   static const char* legacy = getenv("PTX_RAD_LEGACY");
   if (wide && !(legacy && legacy[0] == '1')) return stats ? go(radianceKernel<true>, kRadStack, kRadRays) : go(radianceKernel<false>, kRadStack, kRadRays);
+#endif
+#ifdef PTX_EXPERIMENT_EXCHANGE
+  static const char* exchange = getenv("PTX_EXCHANGE");  // experimental builds: the block-exchange kernel (exchange_kernel.hpp)
+  if (wide && exchange && exchange[0] == '1') return stats ? go(exchangeKernel<true>, kXStack) : go(exchangeKernel<false>, kXStack);
 #endif
   if (wide) return stats ? go(pathKernel<kModeRadiance, true, true>, kLdsStack) : go(pathKernel<kModeRadiance, false, true>, kLdsStack);
   return stats ? go(pathKernel<kModeRadiance, true, false>, kLdsStack) : go(pathKernel<kModeRadiance, false, false>, kLdsStack);

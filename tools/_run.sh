@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python -u -m pytest tests/test_gpu_bench_contract.py -x -q --timeout 280 --timeout-method thread > gpurun_out/r2m_contract.log 2>&1; echo rc=$?; tail -5 gpurun_out/r2m_contract.log
-timeout -k 10 300 python -u bench.py --steps 5 --warmup 1 > gpurun_out/r2m_bench.log 2>&1; echo rc=$?; tail -1 gpurun_out/r2m_bench.log
+export PTX_RAD_LEGACY=1 PTX_EXCHANGE=1
+timeout -k 10 200 python -u tools/wave_profile.py --lib tprof --spp 8 --streams 8 > gpurun_out/r2o_tprof_x.txt 2>&1 && timeout -k 10 200 python -u tools/wave_profile.py --lib wprof --spp 8 --streams 8 > gpurun_out/r2o_wprof_x.txt 2>&1; echo rc=$?; cat gpurun_out/r2o_tprof_x.txt gpurun_out/r2o_wprof_x.txt

@@ -35,6 +35,8 @@ for k, n in enumerate(names):
     it, ln = buf[2 * k], buf[2 * k + 1]
     print(f"{n:12s} {it:14d} {it / max(iters, 1):13.3f} {ln / max(it, 1):11.2f} {ln:14d}")
 tn = ["shade+checks", "decode+issue", "wait (vmcnt/lgkmcnt)", "exit", "enter", "tri", "node", "merge"]
+if os.environ.get("PTX_EXCHANGE") == "1":
+    tn = ["loop top + shading", "post", "barrier after post", "serve: lists, request, fetch issue", "serve: wait for the record", "serve: compute + result", "barrier after serve", "merge"]
 tt = sum(buf[16 + k] for k in range(8))
 if tt:
     print(f"\nwall-clock ticks per region, summed over waves (total {tt:.4g}; per loop iteration {tt / max(iters, 1):.0f})")
