@@ -150,7 +150,7 @@ def main():
     # replicated on every GPU; the flattened arrays come from the on-disk cache when an earlier run (or
     # another rank) on this machine has built them (pt_host.h: pth_scene_create_cached)
     import tempfile
-    scene = ptamd.HostScene(SCENE, cache_dir=os.path.join(tempfile.gettempdir(), "ptx_scene_cache"))
+    scene = ptamd.HostScene(SCENE, cache_dir=os.path.join(tempfile.gettempdir(), f"ptx_scene_cache_{os.getuid()}"))
     dscene = ptamd.DeviceScene(scene.desc_ptr, device=local_rank)
     params = ptamd.make_params(WIDTH, HEIGHT, spp=spp, max_bounces=BOUNCES, seed_mode=ptamd.SEED_STREAM,
                                part_index=rank, part_count=world, sub_streams=sub_streams, frame_spp=frame_spp)

@@ -495,6 +495,7 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
     return fail(PTX_EINVAL, "scene description has a null required array");
   if (d->instance_count == 0 || d->geometry_count == 0 || d->material_count == 0 || d->env_width == 0 || d->env_height == 0)
     return fail(PTX_EINVAL, "scene description has an empty required array");
+  if (d->texture_count != 0 && (!d->textures || !d->texels)) return fail(PTX_EINVAL, "texture_count > 0 with a null texture table or texel array");
   if ((uint64_t)d->env_width * d->env_height >= (1ull << 32)) return fail(PTX_ELIMIT, "environment map too large");
   const double t0 = nowSeconds();
 
@@ -736,6 +737,24 @@ int ptx_check_wide_layout(const ptx_scene_desc* d, uint64_t report[6]) {
   auto check = [&](const ptx_bvh_node* nodes, uint32_t n, bool isTlas, uint32_t primBase) -> int {
     std::vector<WideNode> wide;
     WideInfo info;
+    // this entry point takes descriptions that never went through ptx_create: validate the links first
+    // (children at 2k+1 / 2k+2, in range, every node reached once), as buildWideTree assumes
+    if (n == 0 || (n & 1u) == 0u) return fail(PTX_EINVAL, "node count must be odd and > 0");
+    {
+      std::vector<uint8_t> seen(n, 0);
+      std::vector<uint32_t> walk(1, 0u);
+      seen[0] = 1;
+      while (!walk.empty()) {
+        const uint32_t i = walk.back();
+        walk.pop_back();
+        if (nodes[i].count > 0) continue;
+        const uint32_t l = nodes[i].left_first;
+        if ((l & 1u) == 0u || (uint64_t)l + 1u >= n || seen[l] || seen[l + 1u]) return fail(PTX_EINVAL, "malformed node links");
+        seen[l] = seen[l + 1u] = 1;
+        walk.push_back(l);
+        walk.push_back(l + 1u);
+      }
+    }
     // leaves are referenced by their node index here, so that coverage can be checked against nodes[]
     std::string err = buildWideTree(nodes, n, [&](const ptx_bvh_node& nd) { return kLeafFlag | (uint32_t)(&nd - nodes); }, wide, info);
     (void)isTlas; (void)primBase;

@@ -125,7 +125,7 @@ bool putVec(FILE* f, const std::vector<T>& v) {
 template <typename T>
 bool getVec(FILE* f, std::vector<T>& v, uint64_t limitBytes) {
   uint64_t n = 0;
-  if (fread(&n, sizeof(n), 1, f) != 1 || n * sizeof(T) > limitBytes) return false;
+  if (fread(&n, sizeof(n), 1, f) != 1 || n > limitBytes / sizeof(T)) return false;  // no wrap-around for a huge n
   v.resize(n);
   return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
 }
@@ -159,6 +159,8 @@ bool loadCache(const std::string& path, uint64_t key, pth_scene* s) {
   uint64_t tail = 0;
   ok = ok && fread(&tail, sizeof(tail), 1, f) == 1 && tail == (key ^ 0x5043414348454f4bull);  // written last: a torn file has no tail
   fclose(f);
+  // the header must agree with the arrays it describes: the backend reads env_width * env_height texels
+  ok = ok && h.envWidth != 0 && h.envHeight != 0 && (uint64_t)h.envWidth * h.envHeight * 3u == s->flat.environment.size();
   if (!ok) return false;
   s->flat.envWidth = h.envWidth;
   s->flat.envHeight = h.envHeight;
@@ -206,7 +208,13 @@ int pth_scene_create_cached(int preset, const char* models_dir, const char* env_
   const std::string env = env_path ? env_path : "";
   uint64_t key = 14695981039346656037ull;
   key = fnv(key, kCacheMagic, 8);
-  const uint32_t params[5] = {(uint32_t)preset, scatter_instances, sky_w, sky_h, (uint32_t)sizeof(ptx_instance)};
+  // the file format is the flattened arrays themselves: every record size and a revision of the code that fills
+  // them (flatten.cpp, sah_builder.hpp, sample_scenes.cpp) go into the key, so a changed builder cannot reuse old arrays
+  constexpr uint32_t kFlattenRevision = 2;
+  const uint32_t params[] = {(uint32_t)preset, scatter_instances, sky_w, sky_h, kFlattenRevision,
+                             (uint32_t)sizeof(ptx_instance), (uint32_t)sizeof(ptx_bvh_node), (uint32_t)sizeof(ptx_triangle),
+                             (uint32_t)sizeof(ptx_geometry), (uint32_t)sizeof(ptx_material), (uint32_t)sizeof(ptx_texture),
+                             (uint32_t)sizeof(CacheHeader)};
   key = fnv(key, params, sizeof(params));
   if (preset == 2) {
     key = fnvFile(key, models + "/viking-room/viking_room.obj", "absent");
@@ -216,7 +224,7 @@ int pth_scene_create_cached(int preset, const char* models_dir, const char* env_
     key = fnvFile(key, models + "/bust-of-menelaus.stl", "stand-in bust v1");
   }
   key = fnvFile(key, env, "stand-in sky v1");
-  mkdir(cache_dir, 0777);
+  mkdir(cache_dir, 0700);  // private to the user: the arrays are trusted as far as the checks in loadCache go
   char name[64];
   snprintf(name, sizeof(name), "/scene%d_%016llx.ptxflat", preset, (unsigned long long)key);
   const std::string path = std::string(cache_dir) + name;

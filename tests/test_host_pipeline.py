@@ -205,7 +205,21 @@ def test_flattened_scene_cache(tmp_path):
     again = ptamd.HostScene(2, sky=(64, 32), cache_dir=tmp_path)
     assert not again.cache_hit
     assert os.path.getsize(files[0]) == size
-    for s in (plain, first, second, other, again):
+    # a header whose environment size disagrees with the stored array is not trusted either (the backend would
+    # read env_width * env_height texels): CacheHeader ends with envWidth, envHeight
+    import ctypes as C
+    header = 8 + 8 + C.sizeof(ptamd.Camera) + C.sizeof(ptamd.HostInfo)
+    header = (header + 3) // 4 * 4
+    with open(files[0], "r+b") as f:
+        f.seek(header)
+        w, h = np.frombuffer(f.read(8), dtype=np.uint32)
+        assert (w, h) == (64, 32), "test out of date: CacheHeader layout changed"
+        f.seek(header)
+        f.write(np.array([4096, 4096], dtype=np.uint32).tobytes())
+    lying = ptamd.HostScene(2, sky=(64, 32), cache_dir=tmp_path)
+    assert not lying.cache_hit and lying.desc.env_width == 64
+    assert (os.stat(tmp_path).st_mode & 0o777) in (0o700, 0o755, 0o775, 0o777)  # pytest made it; ours are created 0700
+    for s in (plain, first, second, other, again, lying):
         s.close()
 
 

@@ -50,6 +50,24 @@ def test_malformed_tree_is_rejected_not_looped(scene2):
         nodes[1].left_first, nodes[1].count = saved
 
 
+def test_out_of_range_links_are_rejected_before_the_layout_is_built(scene2):
+    """ptx_check_wide_layout takes descriptions that never went through ptx_create: a root whose children lie
+    outside the node array must be an error, not a read past the array."""
+    d = scene2.desc
+    n = d.blas_node_total
+    nodes = (ptamd.BvhNode * n).from_address(C.addressof(d.blas_nodes.contents))
+    lib = ptamd.backend_lib()
+    lib.ptx_check_wide_layout.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    for bad in (n, n - 1, 2, 0x7FFFFFFF):   # past the end; right child past the end; even (not 2k+1); far away
+        saved = nodes[0].left_first, nodes[0].count
+        try:
+            nodes[0].left_first, nodes[0].count = bad, 0
+            rep = (C.c_uint64 * 6)()
+            assert lib.ptx_check_wide_layout(scene2.desc_ptr, rep) != 0, bad
+        finally:
+            nodes[0].left_first, nodes[0].count = saved
+
+
 @pytest.mark.gpu
 def test_reciprocal_is_ieee_on_its_whole_range():
     lib = ptamd.backend_lib()
