@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-export PTX_RAD_LEGACY=1
-timeout -k 10 300 python -u tools/wave_profile.py --lib wprof --spp 100 --streams 25 > gpurun_out/r2s_wprof.txt 2>&1; echo rc=$?; cat gpurun_out/r2s_wprof.txt
+timeout -k 10 400 python -u -m pytest tests/test_reference_images.py -v -s --timeout 300 --timeout-method thread > gpurun_out/r2v_refimg.log 2>&1; echo rc=$?; grep -E "PASS|FAIL|correlation|Error" gpurun_out/r2v_refimg.log | tail
