@@ -350,8 +350,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
 
       // Record fetch.  The loop is bound by the vector memory path, whose cost is per load instruction
       // and active lane (tools/ubench_gather2.hip: ~45 cycles per divergent 64-lane load whatever its
-      // width), so every lane fetches only what its step uses: nothing for lanes that wait or leave an
-      // instance, three quarters for a triangle.  (Keeping the most visited NodePairs in LDS was tried
+      // width), so every lane fetches only what its step uses: nothing for lanes that wait, three quarters for a triangle.  (Keeping the most visited NodePairs in LDS was tried
       // and lost: the hottest pairs are the ones many lanes of a wave read together, which the memory
       // path already serves as one access.)
       const bool fetch3 = isNode || isTri || isEnter;

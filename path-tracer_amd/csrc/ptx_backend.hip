@@ -134,9 +134,10 @@ int convertTree(const ptx_bvh_node* nodes, uint32_t n, uint32_t primBase, uint32
 }
 
 // Slots the binary-layout walk can touch: slot 0 holds the bottom marker, every internal level of the
-// TLAS and of the BLAS defers at most one child, the instance entry pushes its exit marker -- so sp
-// reaches tlasDepth + blasDepth + 2 -- and every stepping iteration writes slot sp (the write that is
-// not followed by sp++ leaves garbage above the top).  Slots 0 .. depth sum + 2: depth sum + 3 entries.
+// TLAS and of the BLAS defers at most one child -- so sp reaches tlasDepth + blasDepth + 1 -- and every
+// stepping iteration writes slot sp (the write that is not followed by sp++ leaves garbage above the top).
+// The bound keeps the slot of the instance-exit marker that round 1 pushed (no longer pushed: the instance
+// is left by the pop that reaches a TLAS-level entry), as one entry of slack: depth sum + 3 entries.
 inline uint32_t binaryStackBound(uint32_t tlasDepth, uint32_t blasDepth) { return tlasDepth + blasDepth + 3u; }
 
 template <typename T>
