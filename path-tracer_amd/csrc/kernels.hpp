@@ -348,11 +348,12 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
       const bool deep = __any(sp + (WIDE ? 4u : 2u) >= kLdsStack);
       const uint32_t top = stackRead(stk, sp ? sp - 1u : 0u, deep);
 
-      // Record fetch.  The loop is bound by the vector memory path, whose cost is per load instruction
-      // and active lane (tools/ubench_gather2.hip: ~45 cycles per divergent 64-lane load whatever its
-      // width), so every lane fetches only what its step uses: nothing for lanes that wait, three quarters for a triangle.  (Keeping the most visited NodePairs in LDS was tried
-      // and lost: the hottest pairs are the ones many lanes of a wave read together, which the memory
-      // path already serves as one access.)
+      // Record fetch.  The vector memory path charges per load instruction and active lane (tools/ubench_gather2.hip:
+      // ~45 cycles per divergent 64-lane load whatever its width); it bound the binary layout and still runs at
+      // 0.6 of its rate on the wide one, so every lane fetches only what its step uses: nothing for lanes that
+      // wait, three quarters for a triangle.  (Keeping the most visited NodePairs in LDS was tried and lost: the
+      // hottest pairs are the ones many lanes of a wave read together, which the memory path already serves as
+      // one access.)
       const bool fetch3 = isNode || isTri || isEnter;
       const bool fetch4 = isNode || isEnter;
       const uint32_t off16 = isNode ? (WIDE ? sc.wide16 : sc.pairs16) + ref * 4u : (isTri ? sc.tris16 + first * 3u : sc.inst16 + first * 4u);
