@@ -146,7 +146,10 @@ def main():
     import multigpu
     frame_spp = args.spp * world if args.weak else args.spp            # samples per pixel of the whole job
     spp = multigpu.split_samples(frame_spp, world)[rank]               # this rank's share
-    sub_streams = max(1, min(args.sub_streams, spp))
+    # work items of at least two samples: a rank's share of a frame split over 8 GPUs is 12-13 spp, and one-sample
+    # items pay the per-item bookkeeping for every sample (13 spp: 48.6 ms in 7 streams, 49.7 ms in 13; 25 spp: 90.4 ms
+    # in 13 streams, 94.0 ms in 25; profiles/r02/share_streams_ab.txt)
+    sub_streams = max(1, min(args.sub_streams, (spp + 1) // 2))
     # replicated on every GPU; the flattened arrays come from the on-disk cache when an earlier run (or
     # another rank) on this machine has built them (pt_host.h: pth_scene_create_cached)
     import tempfile
