@@ -130,7 +130,7 @@ struct FrameConstants {
   uint32_t subStreams;          // RNG streams per pixel in this launch (>= 1), each a separate work item
   uint32_t sppBase, sppExtra;   // stream k renders sppBase + (k < sppExtra) samples
   uint32_t widthMul, widthShift;  // n / width for n < 2^24: umulhi(n << 8, widthMul) >> widthShift
-  double invSubStreams;           // 1.0 / subStreams
+  double invPixels;               // 1.0 / (width * height)
 };
 
 struct DeviceStats {  // accumulated with atomics by the instrumented kernel variants

@@ -143,10 +143,10 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_X_WAVES) exchangeKernel(Dev
             }
             uint32_t slot = w, k = 0u;
             if (fc.subStreams > 1u) {
-              slot = (uint32_t)((double)w * fc.invSubStreams);
-              k = w - slot * fc.subStreams;
-              if ((int32_t)k < 0) { slot--; k += fc.subStreams; }
-              else if (k >= fc.subStreams) { slot++; k -= fc.subStreams; }
+              k = (uint32_t)((double)w * fc.invPixels);
+              slot = w - k * nPixels;
+              if ((int32_t)slot < 0) { k--; slot += nPixels; }
+              else if (slot >= nPixels) { k++; slot -= nPixels; }
             }
             uint32_t x, y;
             workPixel(fc, slot, x, y);

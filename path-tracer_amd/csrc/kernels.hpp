@@ -251,17 +251,19 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
               havePixel = false;
               break;
             }
-            // item -> (pixel slot, stream): the streams of a pixel are neighbours; slots walk the image in 8x8 blocks.
-            // (Handing the pixels out most expensive first -- priced by the heat-map kernel, counting sort over 256
-            // cost classes -- was built and measured: 474 -> 470 ms with the reference's seeding, 352.6 -> 351.7 ms
-            // with 25 streams, less than the pre-pass costs.  The frame's tail is not late starts of expensive
-            // pixels but the length of the single longest chain; profiles/r02/cost_order_ab.txt.)
+            // item -> (stream, pixel slot): all pixels of stream 0, then of stream 1, ...; slots walk the image in 8x8
+            // blocks.  The streams that hold one sample more (k < sppExtra) come first, so the frame ends with its
+            // shortest items (13 spp in 7 streams: 47.3 ms against 48.7 ms with a pixel's streams side by side;
+            // profiles/r02/stream_major_ab.txt).  (Handing the pixels out most expensive first -- priced by the
+            // heat-map kernel, counting sort over 256 cost classes -- was built and measured: 474 -> 470 ms with the
+            // reference's seeding, 352.6 -> 351.7 ms with 25 streams, less than the pre-pass costs: the tail is the
+            // length of the last items, not late starts of expensive pixels; profiles/r02/cost_order_ab.txt.)
             uint32_t slot = w, k = 0u;
             if (fc.subStreams > 1u) {
-              slot = (uint32_t)((double)w * fc.invSubStreams);  // w < 2^32, exact up to one unit either way
-              k = w - slot * fc.subStreams;
-              if ((int32_t)k < 0) { slot--; k += fc.subStreams; }
-              else if (k >= fc.subStreams) { slot++; k -= fc.subStreams; }
+              k = (uint32_t)((double)w * fc.invPixels);  // w < 2^32: exact up to one unit either way
+              slot = w - k * nPixels;
+              if ((int32_t)slot < 0) { k--; slot += nPixels; }
+              else if (slot >= nPixels) { k++; slot -= nPixels; }
             }
             uint32_t x, y;
             workPixel(fc, slot, x, y);

@@ -243,7 +243,7 @@ int makeFrame(const ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, 
   fc.subStreams = streams;
   fc.sppBase = fc.spp / streams;
   fc.sppExtra = fc.spp % streams;
-  fc.invSubStreams = 1.0 / (double)streams;
+  fc.invPixels = 1.0 / ((double)prm->width * (double)prm->height);
   {
     uint32_t sh = 0;
     while ((1u << sh) < prm->width) sh++;  // width <= 2^24
