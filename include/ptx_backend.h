@@ -276,6 +276,13 @@ int ptx_last_kernel_seconds(ptx_scene* scene, double* seconds);
  *                            directions with the IEEE 1.0f / x for EVERY float whose biased exponent is
  *                            in [1, 252] (the guarded range); *mismatches must come back 0. */
 int ptx_check_wide_layout(const ptx_scene_desc* desc, uint64_t report[6]);
+/* Self-check of the tight TLAS boxes of the radiance path (csrc/tight_bounds.hpp; no counterpart in the reference, which
+ * bounds an instance by the transformed corners of its BLAS box, mesh.cpp:18-41).  Computes the instance bounds on
+ * `device` as ptx_create does and reports: [0] instances, [1] instances whose bounds were recomputed on the host,
+ * [2] of those, how many differ from the device's in any bit (must be 0), [3] TLAS nodes whose tight box is not
+ * inside the reference's box or whose links changed (must be 0), [4] leaf boxes that do not hold the padded bounds
+ * of one of their instances (must be 0), [5] mean leaf volume, tight / reference, in millionths. */
+int ptx_check_tight_tlas(const ptx_scene_desc* desc, int device, uint64_t report[6]);
 int ptx_selftest_reciprocal(int device, uint64_t* mismatches);
 
 /* Replaces the frees at gpuRender.cu:289-310. */

@@ -22,6 +22,7 @@
 #ifdef PTX_EXPERIMENT_EXCHANGE  // DESIGN.md section 3, "block exchange": measured slower, kept for A/B builds only
 #include "exchange_kernel.hpp"
 #endif
+#include "tight_bounds.hpp"
 #include "wide_bvh.hpp"
 
 using namespace ptx;
@@ -150,6 +151,48 @@ size_t arenaReserve(size_t& cursor, size_t count) {
 
 double nowSeconds() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Raw world-space bounds of every instance's transformed vertices, computed on `device` (instanceBoundsKernel):
+// 6 floats per instance, and which instances have usable bounds.  Temporary device buffers only.
+int deviceInstanceBounds(const ptx_scene_desc* d, int device, std::vector<float>& raw, std::vector<uint8_t>& usable) {
+  const uint32_t n = d->instance_count;
+  raw.assign((size_t)n * 6u, 0.0f);
+  usable.assign(n, 0);
+  std::vector<InstanceModel> models(n);
+  for (uint32_t i = 0; i < n; i++) {
+    const ptx_instance& I = d->instances[i];
+    if (I.geometry_id >= d->geometry_count) return fail(PTX_EINVAL, "instance refers to a missing geometry/material");
+    const ptx_geometry& G = d->geometries[I.geometry_id];
+    double M[12];
+    InstanceModel& m = models[i];
+    memset(&m, 0, sizeof(m));
+    if (G.tri_count != 0 && tight_detail::invertAffine(I.inv_model, M)) {
+      for (int k = 0; k < 12; k++) m.m[k] = (float)M[k];
+      m.triOffset = G.tri_offset;
+      m.triCount = G.tri_count;
+      usable[i] = 1;
+    }  // else triCount 0: the kernel writes an inverted box, which padBounds never sees
+  }
+  HIP_TRY(hipSetDevice(device));
+  float *dVerts = nullptr, *dOut = nullptr;
+  InstanceModel* dModels = nullptr;
+  const size_t vertBytes = (size_t)d->triangle_total * sizeof(ptx_triangle);
+  hipError_t e = hipMalloc((void**)&dVerts, vertBytes ? vertBytes : 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&dModels, (size_t)n * sizeof(InstanceModel));
+  if (e == hipSuccess) e = hipMalloc((void**)&dOut, raw.size() * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(dVerts, d->triangles, vertBytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dModels, models.data(), (size_t)n * sizeof(InstanceModel), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    instanceBoundsKernel<<<dim3((n + kBoundsGroup - 1u) / kBoundsGroup), dim3(256)>>>(dVerts, dModels, n, dOut);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(raw.data(), dOut, raw.size() * sizeof(float), hipMemcpyDeviceToHost);
+  if (dVerts) (void)hipFree(dVerts);
+  if (dModels) (void)hipFree(dModels);
+  if (dOut) (void)hipFree(dOut);
+  HIP_TRY(e);
+  return PTX_OK;
 }
 
 }  // namespace
@@ -533,7 +576,20 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
   std::vector<WideInfo> blasWide(d->geometry_count);
   uint32_t blasWideDepth = 0, tlasWideEnd = 0;
   {
-    std::string err = buildWideTree(d->tlas_nodes, d->tlas_node_count,
+    // the radiance path's TLAS: the reference's tree with tight boxes (tight_bounds.hpp); PTX_TIGHT_TLAS=0 keeps
+    // the reference's boxes (A/B measurements)
+    static const char* tightEnv = getenv("PTX_TIGHT_TLAS");
+    std::vector<ptx_bvh_node> tlasTight;
+    if (!(tightEnv && tightEnv[0] == '0')) {
+      std::vector<float> raw;
+      std::vector<uint8_t> usable;
+      if ((rc = deviceInstanceBounds(d, device, raw, usable))) return rc;
+      std::vector<Box3> instBounds;
+      padBounds(raw.data(), usable, instBounds);
+      tlasTight = refitTlas(d, instBounds, nullptr);
+    }
+    const ptx_bvh_node* tlasForWide = tlasTight.empty() ? d->tlas_nodes : tlasTight.data();
+    std::string err = buildWideTree(tlasForWide, d->tlas_node_count,
                                     [&](const ptx_bvh_node& nd) { return makeTlasLeafRef(nd.left_first, nd.count); }, wideNodes, tlasWide);
     tlasWideEnd = (uint32_t)wideNodes.size();
     for (uint32_t g = 0; g < d->geometry_count && err.empty(); g++) {
@@ -728,6 +784,49 @@ int ptx_selftest_reciprocal(int device, uint64_t* mismatches) {
   (void)hipFree(d);
   HIP_TRY(e);
   *mismatches = h;
+  return PTX_OK;
+}
+
+int ptx_check_tight_tlas(const ptx_scene_desc* d, int device, uint64_t report[6]) {
+  if (!d || !report || !d->tlas_nodes || !d->instances || !d->geometries || !d->triangles) return fail(PTX_EINVAL, "null argument");
+  for (int i = 0; i < 6; i++) report[i] = 0;
+  std::vector<NodePair> pairs;
+  TreeInfo info;
+  int rc = convertTree(d->tlas_nodes, d->tlas_node_count, 0u, d->instance_count, true, pairs, info);  // validates the links
+  if (rc) return rc;
+  for (uint32_t g = 0; g < d->geometry_count; g++)
+    if ((uint64_t)d->geometries[g].tri_offset + d->geometries[g].tri_count > d->triangle_total) return fail(PTX_EINVAL, "geometry ranges outside the pooled arrays");
+  std::vector<float> raw, rawHost((size_t)d->instance_count * 6u, 0.0f);
+  std::vector<uint8_t> usable, usableHost(d->instance_count, 0);
+  if ((rc = deviceInstanceBounds(d, device, raw, usable))) return rc;
+  // the same bounds from the host loop, for every instance up to 64 and an even sample of 64 beyond
+  const uint32_t n = d->instance_count, step = n > 64u ? n / 64u : 1u;
+  for (uint32_t i = 0; i < n; i += step) {
+    rawInstanceBoundsHost(d, i, i + 1u, rawHost.data(), usableHost);
+    report[1]++;
+    bool same = usable[i] == usableHost[i];
+    if (same && usable[i])
+      for (int k = 0; k < 6; k++) same = same && raw[6 * (size_t)i + k] == rawHost[6 * (size_t)i + k];
+    if (!same) report[2]++;
+  }
+  std::vector<Box3> inst;
+  padBounds(raw.data(), usable, inst);
+  double ratio = 1.0;
+  const std::vector<ptx_bvh_node> tight = refitTlas(d, inst, &ratio);
+  for (uint32_t i = 0; i < d->tlas_node_count; i++) {
+    const ptx_bvh_node &a = tight[i], &b = d->tlas_nodes[i];
+    bool inside = a.left_first == b.left_first && a.count == b.count;
+    for (int k = 0; k < 3; k++) inside = inside && a.aabb_min[k] >= b.aabb_min[k] && a.aabb_max[k] <= b.aabb_max[k] && a.aabb_min[k] <= a.aabb_max[k];
+    if (!inside) report[3]++;
+    if (a.count > 0)  // a leaf's box holds the padded bounds of its instances, unless the reference's own box cut them
+      for (uint32_t j = 0; j < a.count; j++)
+        for (int k = 0; k < 3; k++)
+          if (usable[a.left_first + j] && (a.aabb_min[k] > fmaxf(inst[a.left_first + j].mn[k], b.aabb_min[k]) ||
+                                           a.aabb_max[k] < fminf(inst[a.left_first + j].mx[k], b.aabb_max[k])))
+            report[4]++;
+  }
+  report[0] = n;
+  report[5] = (uint64_t)(ratio * 1e6);
   return PTX_OK;
 }
 

@@ -248,7 +248,7 @@ _backend = None
 BACKEND_SYMBOLS = [
     "ptx_device_count", "ptx_create", "ptx_render_counts", "ptx_render", "ptx_accumulate_device",
     "ptx_resolve_device", "ptx_counts_device", "ptx_measure", "ptx_last_kernel_seconds", "ptx_destroy",
-    "ptx_last_error", "ptx_version", "ptx_check_wide_layout", "ptx_selftest_reciprocal", "ptx_render_counts_bgr8",
+    "ptx_last_error", "ptx_version", "ptx_check_wide_layout", "ptx_check_tight_tlas", "ptx_selftest_reciprocal", "ptx_render_counts_bgr8",
     "ptx_render_bgr8", "ptx_accumulate_device_noalloc", "ptx_render_multi", "ptx_render_counts_multi",
 ]
 NOALLOC_SCRATCH_BYTES = 128 << 20  # PTX_NOALLOC_SCRATCH_BYTES
