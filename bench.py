@@ -232,7 +232,7 @@ def main():
         # counters of the committed rocprofv3 --pmc passes (profiles/traffic.json, made by tools/make_traffic.py from
         # profiles/r02): per-ray figures of this kernel on this scene / resolution / bounce count, scaled to this
         # launch's exact ray count (the passes ran the 100-spp frame; a rank of an N-GPU job traces fewer samples)
-        traffic = valu = l2_hit = None
+        traffic = valu = l2_hit = lds_bytes = scratch = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
@@ -240,6 +240,8 @@ def main():
             if t.get("workload", "").startswith(f"scene{SCENE}_{WIDTH}x{HEIGHT}_") and t.get("workload", "").endswith(f"_{BOUNCES}b"):
                 traffic = t["hbm_bytes_per_ray"] * stats.rays
                 l2_hit = t.get("l2_hit_rate")
+                lds_bytes = int(t["lds_bytes"]) if t.get("lds_bytes") is not None else None
+                scratch = int(t["scratch_size"]) if t.get("scratch_size") is not None else None
                 insts = t["valu_insts_per_ray"] * stats.rays
                 valu = {"bound": "VALU issue (wave-instructions)", "insts": insts, "per_ray": t["valu_insts_per_ray"],
                         "achieved": insts / avg_kernel / 1e9, "peak": VALU_PEAK_G, "unit": "G wave-instructions/s",
@@ -271,7 +273,7 @@ def main():
                 "frac": traffic / avg_kernel / 1e9 / HBM_PEAK_GBS if traffic else None, "traffic": traffic,
                 "traffic_is": "bytes requested by the L2 from the memory side (FETCH_SIZE x 2 + WRITE_SIZE), Infinity-Cache hits included",
                 "binding": "valu",
-                "l2_hit_rate": l2_hit, "waves_per_simd": 5, "vgprs": 96, "lds_bytes_per_block": 26624, "scratch_bytes_per_lane": 0,
+                "l2_hit_rate": l2_hit, "lds_bytes_per_block": lds_bytes, "scratch_bytes_per_lane": scratch,
                 "kernel": "ptx::pathKernel<1, false, true>", "kernel_ms": avg_kernel * 1e3,
                 "l1_level": {"algorithmic_bytes": alg, "achieved": alg / avg_kernel / 1e9, "unit": "GB/s",
                              "note": "bytes the steps consume at the register file; re-served from L1 / L2 / Infinity Cache"},
