@@ -281,7 +281,8 @@ int ptx_check_wide_layout(const ptx_scene_desc* desc, uint64_t report[6]);
  * `device` as ptx_create does and reports: [0] instances, [1] instances whose bounds were recomputed on the host,
  * [2] of those, how many differ from the device's in any bit (must be 0), [3] TLAS nodes whose tight box is not
  * inside the reference's box or whose links changed (must be 0), [4] leaf boxes that do not hold the padded bounds
- * of one of their instances (must be 0), [5] mean leaf volume, tight / reference, in millionths. */
+ * of one of their instances (must be 0), [5] mean leaf volume, tight / reference, in millionths.  device < 0: no GPU
+ * is touched, the bounds come from the host loop (small scenes: CPU tests of the refit). */
 int ptx_check_tight_tlas(const ptx_scene_desc* desc, int device, uint64_t report[6]);
 int ptx_selftest_reciprocal(int device, uint64_t* mismatches);
 

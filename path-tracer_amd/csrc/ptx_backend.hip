@@ -796,9 +796,17 @@ int ptx_check_tight_tlas(const ptx_scene_desc* d, int device, uint64_t report[6]
   if (rc) return rc;
   for (uint32_t g = 0; g < d->geometry_count; g++)
     if ((uint64_t)d->geometries[g].tri_offset + d->geometries[g].tri_count > d->triangle_total) return fail(PTX_EINVAL, "geometry ranges outside the pooled arrays");
+  for (uint32_t i = 0; i < d->instance_count; i++)
+    if (d->instances[i].geometry_id >= d->geometry_count) return fail(PTX_EINVAL, "instance refers to a missing geometry/material");
   std::vector<float> raw, rawHost((size_t)d->instance_count * 6u, 0.0f);
   std::vector<uint8_t> usable, usableHost(d->instance_count, 0);
-  if ((rc = deviceInstanceBounds(d, device, raw, usable))) return rc;
+  if (device < 0) {  // no GPU: the host loop for every instance (slow for large scenes; CPU tests use small ones)
+    raw.assign((size_t)d->instance_count * 6u, 0.0f);
+    usable.assign(d->instance_count, 0);
+    rawInstanceBoundsHost(d, 0u, d->instance_count, raw.data(), usable);
+  } else if ((rc = deviceInstanceBounds(d, device, raw, usable))) {
+    return rc;
+  }
   // the same bounds from the host loop, for every instance up to 64 and an even sample of 64 beyond
   const uint32_t n = d->instance_count, step = n > 64u ? n / 64u : 1u;
   for (uint32_t i = 0; i < n; i += step) {

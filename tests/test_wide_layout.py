@@ -68,6 +68,22 @@ def test_out_of_range_links_are_rejected_before_the_layout_is_built(scene2):
             nodes[0].left_first, nodes[0].count = saved
 
 
+@pytest.mark.parametrize("which", ["scene2", "scene0"])
+def test_tight_tlas_refit_invariants_on_the_host(which, request):
+    """csrc/tight_bounds.hpp without a GPU (device -1: bounds from the host loop): no tight box leaves the reference's
+    box, the links are untouched, every leaf holds the padded bounds of its instances."""
+    scene = request.getfixturevalue(which)
+    lib = ptamd.backend_lib()
+    lib.ptx_check_tight_tlas.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    rep = (C.c_uint64 * 6)()
+    assert lib.ptx_check_tight_tlas(scene.desc_ptr, -1, rep) == 0, lib.ptx_last_error()
+    n, checked, differ, outside, leaf_misses, ratio = [int(v) for v in rep]
+    assert n == scene.desc.instance_count and checked == n and differ == 0 and outside == 0 and leaf_misses == 0
+    assert 0 < ratio <= 1_000_000
+    if which == "scene0":
+        assert ratio < 900_000   # three rotated busts: the reference's boxes are a sixth larger
+
+
 @pytest.mark.gpu
 def test_reciprocal_is_ieee_on_its_whole_range():
     lib = ptamd.backend_lib()
