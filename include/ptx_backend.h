@@ -279,7 +279,8 @@ int ptx_check_wide_layout(const ptx_scene_desc* desc, uint64_t report[6]);
 /* Self-check of the tight TLAS boxes of the radiance path (csrc/tight_bounds.hpp; no counterpart in the reference, which
  * bounds an instance by the transformed corners of its BLAS box, mesh.cpp:18-41).  Computes the instance bounds on
  * `device` as ptx_create does and reports: [0] instances, [1] instances whose bounds were recomputed on the host,
- * [2] of those, how many differ from the device's in any bit (must be 0), [3] TLAS nodes whose tight box is not
+ * [2] of those, how many differ from the device's in any bit -- or, when the scene is so large that BLAS box corners
+ *     stand in for the vertices, are not contained in the device's (must be 0), [3] TLAS nodes whose tight box is not
  * inside the reference's box or whose links changed (must be 0), [4] leaf boxes that do not hold the padded bounds
  * of one of their instances (must be 0), [5] mean leaf volume, tight / reference, in millionths.  device < 0: no GPU
  * is touched, the bounds come from the host loop (small scenes: CPU tests of the refit). */

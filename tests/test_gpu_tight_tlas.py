@@ -32,6 +32,37 @@ def test_tight_boxes_are_exact_and_inside_the_reference_s(gpu_scenes, preset):
         assert ratio < 600_000  # rotated busts: the reference's boxes have about twice the volume
 
 
+def test_box_corners_stand_in_for_the_vertices_of_very_large_scenes(tmp_path):
+    """Beyond 4e10 triangle-instance pairs ptx_create bounds an instance by the corners of its BLAS boxes eight levels
+    down instead of its vertices (forced here with PTX_TIGHT_EXACT_BUDGET=0): still conservative, still the same image."""
+    code = r"""
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %(py)r)
+import ptamd
+s = ptamd.HostScene(1, scatter_instances=400)
+lib = ptamd.backend_lib()
+lib.ptx_check_tight_tlas.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+rep = (C.c_uint64 * 6)()
+assert lib.ptx_check_tight_tlas(s.desc_ptr, 0, rep) == 0, lib.ptx_last_error()
+d = ptamd.DeviceScene(s.desc_ptr)
+img, _ = d.render(s.camera, ptamd.make_params(160, 96, spp=4, max_bounces=6))
+np.save(%(out)r, img)
+print(*[int(v) for v in rep])
+"""
+    res = {}
+    for name, env in (("standin", {"PTX_TIGHT_EXACT_BUDGET": "0"}), ("exact", {})):
+        out = str(tmp_path / f"{name}.npy")
+        r = subprocess.run([sys.executable, "-c", code % {"py": os.path.join(os.path.dirname(HERE), "path-tracer_amd", "py"), "out": out}],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-1500:]
+        res[name] = (np.load(out), [int(v) for v in r.stdout.split()[-6:]])
+    for name in res:
+        n, checked, differ, outside, leaf_misses, ratio = res[name][1]
+        assert n == 400 and checked >= 64 and differ == 0 and outside == 0 and leaf_misses == 0, (name, res[name][1])
+    assert res["exact"][1][5] < res["standin"][1][5] < 1_000_000     # looser than the vertices, tighter than the reference
+    assert float((res["exact"][0] == res["standin"][0]).all(axis=2).mean()) >= 0.999
+
+
 CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, %(py)r)
