@@ -34,7 +34,7 @@ def grade(c):
 class FloorScene:
     """ptx_scene_desc of the floor; keeps the arrays alive."""
 
-    def __init__(self, albedo, sky, metalness=0.0, roughness=1.0, half=50.0):
+    def __init__(self, albedo, sky, metalness=0.0, roughness=1.0, half=50.0, env=None, textures=None, emissive=(0, 0, 0), model=None):
         self.tlas = (ptamd.BvhNode * 1)()
         self.blas = (ptamd.BvhNode * 1)()
         for n, cnt in ((self.tlas[0], 1), (self.blas[0], 2)):
@@ -52,15 +52,44 @@ class FloorScene:
         self.inst = (ptamd.Instance * 1)()
         self.inst[0].inv_model[:] = IDENTITY
         self.inst[0].normal_matrix[:] = IDENTITY
+        if model is not None:
+            # mesh.cpp:6-16: the instance keeps inverse(model) and transpose(inverse(model)); GLM matrices are column-major;
+            # the TLAS leaf bounds the eight (here four) transformed corners of the BLAS root box (mesh.cpp:18-41)
+            inv = np.linalg.inv(np.asarray(model, dtype=np.float64))
+            self.inst[0].inv_model[:] = [float(c) for c in inv.T.reshape(-1)]
+            self.inst[0].normal_matrix[:] = [float(c) for c in inv.reshape(-1)]   # transpose(inv), column-major = inv row-major
+            corners = np.array([[sx * half, 0.0, sz * half, 1.0] for sx in (-1, 1) for sz in (-1, 1)]) @ np.asarray(model, dtype=np.float64).T
+            self.tlas[0].aabb_min[:] = [float(c) for c in corners[:, :3].min(axis=0) - 1e-4]
+            self.tlas[0].aabb_max[:] = [float(c) for c in corners[:, :3].max(axis=0) + 1e-4]
+            self.inv_model = inv
         self.inst[0].geometry_id = self.inst[0].material_id = 0
         self.mat = (ptamd.Material * 1)()
         m = self.mat[0]
         m.albedo[:] = albedo
         m.metalness, m.roughness = metalness, roughness
-        m.emissive[:] = (0, 0, 0)
+        m.emissive[:] = emissive
         m.f0[:] = (0.04, 0.04, 0.04)
         m.albedo_texture = m.emissive_texture = 0xFFFFFFFF
-        self.env = (C.c_float * 6)(*(list(sky) * 2))
+        self.half = half
+        if textures is not None:
+            # textures = (albedo texels (h, w, 3), emissive texels (h', w', 3), uv scale, uv offset): the floor's corner
+            # (-half, -half) has uv = offset, the opposite one offset + scale, linear in between
+            ta, te, self.uv_scale, self.uv_offset = textures
+            self.tex = (ptamd.Texture * 2)()
+            self.tex[0].width, self.tex[0].height, self.tex[0].texel_offset = ta.shape[1], ta.shape[0], 0
+            self.tex[1].width, self.tex[1].height, self.tex[1].texel_offset = te.shape[1], te.shape[0], ta.shape[0] * ta.shape[1]
+            self.texel_array = np.ascontiguousarray(np.concatenate([ta.reshape(-1, 3), te.reshape(-1, 3)]), dtype=np.float32)
+            uv = []
+            for t in self.tris:
+                for v in (t.v0, t.v1, t.v2):
+                    uv += [self.uv_offset + self.uv_scale * (v[0] + half) / (2 * half), self.uv_offset + self.uv_scale * (v[2] + half) / (2 * half)]
+            self.uv_array = np.array(uv, dtype=np.float32)
+            g.vtx_uv_offset = 0
+            m.albedo_texture, m.emissive_texture = 0, 1
+        if env is None:
+            env = np.array([[sky, sky]], dtype=np.float32)          # 2 x 1 texels of one colour
+        self.env_array = np.ascontiguousarray(env, dtype=np.float32)
+        self.env = self.env_array.ctypes.data_as(C.POINTER(C.c_float))
         d = self.desc = ptamd.SceneDesc()
         d.tlas_nodes, d.tlas_node_count = self.tlas, 1
         d.instances, d.instance_count = self.inst, 1
@@ -69,7 +98,11 @@ class FloorScene:
         d.triangles, d.triangle_total = self.tris, 2
         d.face_normals, d.face_normal_total = self.face_normals, 2
         d.materials, d.material_count = self.mat, 1
-        d.environment, d.env_width, d.env_height = self.env, 2, 1
+        if textures is not None:
+            d.textures, d.texture_count = self.tex, 2
+            d.texels, d.texel_total = self.texel_array.ctypes.data_as(C.POINTER(C.c_float)), len(self.texel_array)
+            d.vtx_uvs, d.vtx_uv_total = self.uv_array.ctypes.data_as(C.POINTER(C.c_float)), 6
+        d.environment, d.env_width, d.env_height = self.env, self.env_array.shape[1], self.env_array.shape[0]
         self.desc_ptr = C.pointer(d)
         self.camera = ptamd.Camera()
         self.camera.position[:] = (0.3, 5.0, -0.2)
@@ -140,3 +173,179 @@ def test_mirror_floor_keeps_energy_below_one(torch_first):
             assert np.abs(a - ref).max() < 1e-3 * 64
         finally:
             dev.close()
+
+
+def primary_directions(cam, width, height):
+    """camera.hpp:8-20 and gpuRender.cu:118-137 in float64, one sample per pixel (no jitter): (height, width, 3)."""
+    pos, at, up = (np.array(list(v), dtype=np.float64) for v in (cam.position, cam.target, cam.up))
+    z = (at - pos) / np.linalg.norm(at - pos)
+    x = np.cross(z, up)
+    x /= np.linalg.norm(x)
+    y = np.cross(x, z)
+    px, py = np.meshgrid(np.arange(width, dtype=np.float64), np.arange(height, dtype=np.float64))
+    v = np.stack([px - 0.5 * width, py - 0.5 * height,
+                  np.full_like(px, -(0.5 * height) / np.tan(0.5 * np.radians(cam.fov_deg)))], axis=-1)
+    v /= np.linalg.norm(v, axis=-1, keepdims=True)
+    return v[..., 0:1] * x + v[..., 1:2] * y + v[..., 2:3] * (-z)
+
+
+def environment_texels(d, env_w, env_h):
+    """main.cpp:54-75 / gpuRender.cu:14-22 in float64: the direction turned by pi about Y, then longitude / latitude."""
+    u = (env_w * (np.arctan2(-d[..., 2], -d[..., 0]) / (2.0 * np.pi) + 0.5)).astype(np.int64)
+    v = (env_h * np.arccos(np.clip(d[..., 1], -1.0, 1.0)) / np.pi).astype(np.int64)
+    return np.minimum(u + v * env_w, env_w * env_h - 1)
+
+
+SKY_RES = (192, 128)
+SKY_VIEWS = [((0.3, 9.0, 0.4), (0, 0, 1), 90.0), ((5.0, 6.5, 1.0), (0, 1, 0), 50.0),
+             ((-3.0, 5.5, -4.0), (0, 1, 0), 100.0), ((0.0, 5.2, 8.0), (0.2, 1, 0), 75.0)]
+
+
+def sky_view(target, up, fov):
+    """The floor scene under a 16 x 8 environment of random colours, seen from 5 above the floor; returns the scene,
+    the expected frame at one sample per pixel and the mask of the pixels that look above the horizon."""
+    env_w, env_h = 16, 8
+    env = np.random.default_rng(11).uniform(0.05, 3.0, size=(env_h, env_w, 3)).astype(np.float32)
+    sc = FloorScene((0.5, 0.5, 0.5), (1, 1, 1), env=env)
+    sc.camera.position[:] = (0.0, 5.0, 0.0)
+    sc.camera.target[:] = target
+    n = float(np.linalg.norm(up))
+    sc.camera.up[:] = [c / n for c in up]
+    sc.camera.fov_deg = fov
+    d = primary_directions(sc.camera, *SKY_RES)
+    expect = grade(env.reshape(-1, 3)[environment_texels(d, env_w, env_h)])
+    sky = d[..., 1] > 0.02                                            # the rest may see the floor
+    assert sky.mean() > 0.4
+    return sc, expect, sky
+
+
+@pytest.mark.parametrize("target,up,fov", SKY_VIEWS)
+def test_sky_only_views_show_the_environment_map(torch_first, target, up, fov):
+    """Rays that leave upwards from above the floor hit nothing: the pixel is grade(environment texel) and the texel
+    follows from the camera and the environment mapping alone, computed here in numpy from the reference's formulas.
+    Pins camera basis, field of view, pixel centres, image orientation and the orientation of the environment map
+    (the turn by pi about Y, which row is up, which way the longitude runs) on the GPU without the oracle."""
+    sc, expect, sky = sky_view(target, up, fov)
+    W, H = SKY_RES
+    dev = ptamd.DeviceScene(sc.desc_ptr)
+    try:
+        p = ptamd.make_params(W, H, spp=1, max_bounces=6)
+        img, _ = dev.render(sc.camera, p)
+    finally:
+        dev.close()
+    same = np.abs(img - expect.astype(np.float32)).max(axis=2) < 2e-6
+    bad = int((~same & sky).sum())
+    print(f"sky pixels {int(sky.sum())}, differing {bad}")
+    # a direction within rounding of a texel border may fall either side in fp32: a handful of pixels at most
+    assert bad <= sky.sum() // 1000, bad
+    # and the oracle agrees with both
+    ref, _ = ob.render(sc, p, seed_mode=p.seed_mode)
+    assert int(((np.abs(ref - expect.astype(np.float32)).max(axis=2) >= 2e-6) & sky).sum()) <= sky.sum() // 1000
+
+
+TEX_RES = (160, 120)
+
+
+def textured_floor():
+    """A floor with an albedo and an emissive texture under a uniform sky, seen from above; returns the scene, the
+    expected frame at one sample per pixel -- grade((albedo * texel_a(uv) + emissive * texel_e(uv)) * sky), uv from
+    the hit point, texel from image.hpp:27-35 -- and the mask of the pixels whose texel is not in doubt."""
+    rng = np.random.default_rng(5)
+    ta = rng.uniform(0.1, 1.0, size=(4, 8, 3)).astype(np.float32)
+    te = rng.uniform(0.0, 2.0, size=(3, 5, 3)).astype(np.float32)
+    albedo, emissive, sky = np.array((0.9, 0.7, 0.5)), np.array((0.2, 0.4, 0.6)), np.array((1.5, 1.0, 0.7))
+    sc = FloorScene(albedo, sky, textures=(ta, te, 3.0, -0.75), emissive=emissive, half=4.0)
+    sc.camera.position[:] = (0.4, 6.0, -0.3)
+    sc.camera.target[:] = (0.0, 0.0, 0.2)
+    sc.camera.fov_deg = 50.0
+    d = primary_directions(sc.camera, *TEX_RES)
+    pos = np.array(list(sc.camera.position), dtype=np.float64)
+    t = -pos[1] / d[..., 1]
+    x, z = pos[0] + t * d[..., 0], pos[2] + t * d[..., 2]
+    on_floor = (np.abs(x) < sc.half - 1e-3) & (np.abs(z) < sc.half - 1e-3)
+    u = sc.uv_offset + sc.uv_scale * (x + sc.half) / (2 * sc.half)
+    v = sc.uv_offset + sc.uv_scale * (z + sc.half) / (2 * sc.half)
+    fu, fv = u - np.floor(u), v - np.floor(v)                          # glm::fract
+    sure = on_floor
+    texel = []
+    for tex in (ta, te):
+        h, w = tex.shape[:2]
+        cx, cy = fu * w, fv * h
+        # within 1e-4 of a texel border fp32 may fall either side
+        sure = sure & (np.abs(cx - np.round(cx)) > 1e-4) & (np.abs(cy - np.round(cy)) > 1e-4)
+        idx = np.clip(cy.astype(np.int64) * w + cx.astype(np.int64), 0, w * h - 1)
+        texel.append(tex.reshape(-1, 3)[idx])
+    expect = grade((albedo * texel[0] + emissive * texel[1]) * sky)
+    assert sure.mean() > 0.5
+    return sc, expect, sure
+
+
+def test_textured_emissive_floor(torch_first):
+    """Texture coordinates, their wrap-around (uv runs from -0.75 to 2.25), the texel addressing and the emissive
+    term, against numpy: every pixel whose texel is not within rounding of a border must be the closed form."""
+    sc, expect, sure = textured_floor()
+    dev = ptamd.DeviceScene(sc.desc_ptr)
+    try:
+        p = ptamd.make_params(*TEX_RES, spp=1, max_bounces=6)
+        img, _ = dev.render(sc.camera, p)
+    finally:
+        dev.close()
+    err = np.abs(img - expect.astype(np.float32)).max(axis=2)
+    assert float(err[sure].max()) < 2e-6, (int((err[sure] >= 2e-6).sum()), int(sure.sum()))
+
+
+MODEL_RES = (200, 140)
+
+
+def placed_floor():
+    """The floor as an instance that is scaled, turned about two axes and moved (gpuRender.cu / intersection.hpp:150-157:
+    the ray goes into the instance's space through inverse(model), the normal comes back through its transpose).
+    Returns the scene, the expected frame -- grade(albedo * sky) where the ray meets the placed square, grade(sky)
+    elsewhere -- the mask of the pixels safely inside or outside the silhouette, and the mask of those inside."""
+    ca, sa, cb, sb = np.cos(0.6), np.sin(0.6), np.cos(-0.35), np.sin(-0.35)
+    rot_z = np.array([[ca, -sa, 0, 0], [sa, ca, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+    rot_x = np.array([[1, 0, 0, 0], [0, cb, -sb, 0], [0, sb, cb, 0], [0, 0, 0, 1.0]])
+    scale = np.diag([1.5, 1.0, 0.6, 1.0])
+    move = np.eye(4)
+    move[:3, 3] = (0.7, -0.4, 1.1)
+    model = move @ rot_z @ rot_x @ scale
+    albedo, sky = np.array((0.6, 0.3, 0.8)), np.array((1.2, 0.9, 0.5))
+    sc = FloorScene(albedo, sky, half=2.0, model=model)
+    sc.camera.position[:] = (0.5, 7.0, -1.0)
+    sc.camera.target[:] = (0.6, 0.0, 0.9)
+    sc.camera.fov_deg = 55.0
+    d = primary_directions(sc.camera, *MODEL_RES)
+    pos = np.array(list(sc.camera.position) + [1.0], dtype=np.float64)
+    o = sc.inv_model @ pos
+    dl = d @ sc.inv_model[:3, :3].T
+    t = -o[1] / dl[..., 1]
+    x, z = o[0] + t * dl[..., 0], o[2] + t * dl[..., 2]
+    edge = np.maximum(np.abs(x), np.abs(z)) - sc.half                  # < 0 inside the square
+    inside = (t > 0) & (edge < 0)
+    sure = np.abs(edge) > 1e-3
+    expect = np.where(inside[..., None], grade(albedo * sky), grade(sky))
+    assert 0.1 < inside.mean() < 0.85
+    return sc, expect, sure, inside
+
+
+def test_placed_floor_instance_transform(torch_first):
+    sc, expect, sure, inside = placed_floor()
+    dev = ptamd.DeviceScene(sc.desc_ptr)
+    try:
+        for spp, streams in ((1, 0), (6, 3)):
+            p = ptamd.make_params(*MODEL_RES, spp=spp, max_bounces=6, seed_mode=ptamd.SEED_STREAM if streams else ptamd.SEED_REFERENCE_GPU,
+                                  sub_streams=streams)
+            img, _ = dev.render(sc.camera, p)
+            err = np.abs(img - expect.astype(np.float32)).max(axis=2)
+            if spp == 1:
+                assert float(err[sure].max()) < 2e-6, (int((err[sure] >= 2e-6).sum()), int(sure.sum()))
+            else:  # jittered samples: only pixels a whole pixel away from the silhouette are certain; the interior is
+                from scipy import ndimage as ndi
+                core = ndi.binary_erosion(inside, iterations=2) | ndi.binary_erosion(~inside, iterations=2)
+                assert float(err[core].max()) < 2e-6
+        # a wrong normal (matrix transposed, say) would send bounces back into the square: a second hit, albedo squared
+        m = dev.measure(sc.camera, ptamd.make_params(*MODEL_RES, spp=1, max_bounces=6))
+        assert m.hits == int(inside.sum()) or abs(int(m.hits) - int(inside.sum())) <= int((~sure).sum())
+        assert m.misses == MODEL_RES[0] * MODEL_RES[1]                   # every path ends in the sky
+    finally:
+        dev.close()

@@ -7,7 +7,7 @@ import pytest
 
 import oracle_binding as ob
 import ptamd
-from test_gpu_analytic import FloorScene, grade
+from test_gpu_analytic import SKY_RES, SKY_VIEWS, MODEL_RES, TEX_RES, FloorScene, grade, placed_floor, sky_view, textured_floor
 
 
 @pytest.mark.parametrize("albedo,sky", [((0.5, 0.25, 0.75), (0.8, 0.8, 0.8)), ((1.0, 1.0, 1.0), (2.0, 0.5, 0.1))])
@@ -27,3 +27,37 @@ def test_mirror_floor_energy_oracle():
         acc, _ = ob.accumulate(sc, ptamd.make_params(64, 48, spp=32, max_bounces=2), seed_mode=ptamd.SEED_REFERENCE_GPU, threads=2)
         mean = acc[..., :3].sum() / (3.0 * acc[..., 3].sum())
         assert lo < mean <= hi + 1e-3
+
+
+@pytest.mark.parametrize("target,up,fov", SKY_VIEWS)
+def test_sky_only_views_show_the_environment_map_oracle(target, up, fov):
+    """Camera basis, pixel centres, image orientation and the orientation of the environment map against the
+    reference's formulas restated in numpy (test_gpu_analytic.py: primary_directions, environment_texels)."""
+    sc, expect, sky = sky_view(target, up, fov)
+    img, _ = ob.render(sc, ptamd.make_params(*SKY_RES, spp=1, max_bounces=6), seed_mode=ptamd.SEED_REFERENCE_GPU, threads=2)
+    bad = int(((np.abs(img - expect.astype(np.float32)).max(axis=2) >= 2e-6) & sky).sum())
+    assert bad <= sky.sum() // 1000, bad
+    # upside down or mirrored it is another picture: the check has teeth
+    assert ((np.abs(img[::-1] - expect).max(axis=2) >= 2e-6) & sky).mean() > 0.2
+    assert ((np.abs(img[:, ::-1] - expect).max(axis=2) >= 2e-6) & sky).mean() > 0.2
+
+
+def test_textured_emissive_floor_oracle():
+    """Texture coordinates, wrap-around, texel addressing and the emissive term against numpy (geometry.cpp:69-87,
+    image.hpp:27-35, gpuRender.cu:60-66 and :107)."""
+    sc, expect, sure = textured_floor()
+    img, _ = ob.render(sc, ptamd.make_params(*TEX_RES, spp=1, max_bounces=6), seed_mode=ptamd.SEED_REFERENCE_GPU, threads=2)
+    err = np.abs(img - expect.astype(np.float32)).max(axis=2)
+    assert float(err[sure].max()) < 2e-6, (int((err[sure] >= 2e-6).sum()), int(sure.sum()))
+    # the texture laid the other way round is another picture
+    assert (np.abs(img - expect[:, ::-1]).max(axis=2)[sure] >= 2e-6).mean() > 0.3
+
+
+def test_placed_floor_instance_transform_oracle():
+    """Instance transform (inverse(model) for the ray, its transpose for the normal) against the silhouette and the
+    colours computed in numpy."""
+    sc, expect, sure, inside = placed_floor()
+    img, st = ob.render(sc, ptamd.make_params(*MODEL_RES, spp=1, max_bounces=6), seed_mode=ptamd.SEED_REFERENCE_GPU, threads=2)
+    err = np.abs(img - expect.astype(np.float32)).max(axis=2)
+    assert float(err[sure].max()) < 2e-6, (int((err[sure] >= 2e-6).sum()), int(sure.sum()))
+    assert abs(int(st.hits) - int(inside.sum())) <= int((~sure).sum()) and st.misses == MODEL_RES[0] * MODEL_RES[1]
