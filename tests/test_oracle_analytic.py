@@ -7,7 +7,8 @@ import pytest
 
 import oracle_binding as ob
 import ptamd
-from test_gpu_analytic import SKY_RES, SKY_VIEWS, MODEL_RES, TEX_RES, FloorScene, grade, placed_floor, sky_view, textured_floor
+from test_gpu_analytic import (LOBE_CASES, LOBE_RES, LOBE_SPP, lobe_scene, MIRROR_RES, MODEL_RES, SKY_RES, SKY_VIEWS, TEX_RES, FloorScene, check_near_mirror, grade,
+                               near_mirror_floor, placed_floor, sky_view, textured_floor)
 
 
 @pytest.mark.parametrize("albedo,sky", [((0.5, 0.25, 0.75), (0.8, 0.8, 0.8)), ((1.0, 1.0, 1.0), (2.0, 0.5, 0.1))])
@@ -61,3 +62,23 @@ def test_placed_floor_instance_transform_oracle():
     err = np.abs(img - expect.astype(np.float32)).max(axis=2)
     assert float(err[sure].max()) < 2e-6, (int((err[sure] >= 2e-6).sum()), int(sure.sum()))
     assert abs(int(st.hits) - int(inside.sum())) <= int((~sure).sum()) and st.misses == MODEL_RES[0] * MODEL_RES[1]
+
+
+def test_near_mirror_floor_reflection_fresnel_and_smith_oracle():
+    """The GGX branch in its mirror limit: reflection direction, Schlick's Fresnel with F0 = albedo and Smith's G, as
+    functions of the angle of incidence, against numpy."""
+    sc, expect, floor = near_mirror_floor()
+    img, _ = ob.render(sc, ptamd.make_params(*MIRROR_RES, spp=1, max_bounces=2), seed_mode=ptamd.SEED_REFERENCE_GPU, threads=2)
+    check_near_mirror(img, expect, floor)
+    # the check has teeth: the same frame with the environment mirrored left to right is far off
+    assert np.median(np.abs(img[:, ::-1] - expect).max(axis=2)[floor & floor[:, ::-1]]) > 1e-2
+
+
+@pytest.mark.parametrize("metalness,roughness", LOBE_CASES)
+def test_sampled_mean_is_the_integral_of_the_lobe_oracle(metalness, roughness):
+    """Cosine-weighted and GGX sampling, the tangent frame and the sample weights: the mean of 196,608 samples against
+    the quadrature of the lobe times the environment (test_gpu_analytic.py: lobe_scene)."""
+    sc, expect = lobe_scene(metalness, roughness)
+    acc, _ = ob.accumulate(sc, ptamd.make_params(*LOBE_RES, spp=LOBE_SPP, max_bounces=2), seed_mode=ptamd.SEED_REFERENCE_GPU, threads=4)
+    got = acc[..., :3].sum(axis=(0, 1)).astype(np.float64) / float(acc[..., 3].sum())
+    assert np.abs(got / expect - 1.0).max() < 0.01, got / expect
