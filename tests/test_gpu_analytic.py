@@ -34,7 +34,7 @@ def grade(c):
 class FloorScene:
     """ptx_scene_desc of the floor; keeps the arrays alive."""
 
-    def __init__(self, albedo, sky, metalness=0.0, roughness=1.0, half=50.0, env=None, textures=None, emissive=(0, 0, 0), model=None):
+    def __init__(self, albedo, sky, metalness=0.0, roughness=1.0, half=50.0, env=None, textures=None, emissive=(0, 0, 0), model=None, corner_normal=None):
         self.tlas = (ptamd.BvhNode * 1)()
         self.blas = (ptamd.BvhNode * 1)()
         for n, cnt in ((self.tlas[0], 1), (self.blas[0], 2)):
@@ -71,6 +71,10 @@ class FloorScene:
         m.f0[:] = (0.04, 0.04, 0.04)
         m.albedo_texture = m.emissive_texture = 0xFFFFFFFF
         self.half = half
+        if corner_normal is not None:
+            # one normal per triangle corner (geometry.cpp:69-87), a function of the corner's position: not normalised
+            self.normal_array = np.array([corner_normal(v[0], v[2]) for t in self.tris for v in (t.v0, t.v1, t.v2)], dtype=np.float32)
+            g.vtx_normal_offset = 0
         if textures is not None:
             # textures = (albedo texels (h, w, 3), emissive texels (h', w', 3), uv scale, uv offset): the floor's corner
             # (-half, -half) has uv = offset, the opposite one offset + scale, linear in between
@@ -102,6 +106,8 @@ class FloorScene:
             d.textures, d.texture_count = self.tex, 2
             d.texels, d.texel_total = self.texel_array.ctypes.data_as(C.POINTER(C.c_float)), len(self.texel_array)
             d.vtx_uvs, d.vtx_uv_total = self.uv_array.ctypes.data_as(C.POINTER(C.c_float)), 6
+        if corner_normal is not None:
+            d.vtx_normals, d.vtx_normal_total = self.normal_array.ctypes.data_as(C.POINTER(C.c_float)), 6
         d.environment, d.env_width, d.env_height = self.env, self.env_array.shape[1], self.env_array.shape[0]
         self.desc_ptr = C.pointer(d)
         self.camera = ptamd.Camera()
@@ -458,3 +464,51 @@ def test_sampled_mean_is_the_integral_of_the_lobe(torch_first, metalness, roughn
             assert np.abs(got / expect - 1.0).max() < 0.01
     finally:
         dev.close()
+
+
+def bumpy_mirror_floor():
+    """The exact-mirror floor again, with a normal per corner that leans outwards: the shading normal is the normalised
+    barycentric mix  b.x * n1 + b.y * n2 + (1 - b.x - b.y) * n0  (geometry.cpp:69-87, b from Moeller-Trumbore,
+    intersection.hpp:9-44), bilinear in the hit point on each of the two triangles.  Returns scene, expected frame and
+    the mask of the pixels that are certain (on the floor, off the diagonal, reflected ray leaving upwards)."""
+    env_w, env_h = 6, 3
+    env = np.random.default_rng(29).uniform(0.2, 2.5, size=(env_h, env_w, 3)).astype(np.float32)
+    albedo, rough, half = np.array((0.8, 0.6, 0.3)), 1e-4, 3.0
+    lean = lambda x, z: (0.5 * x / half, 1.3, -0.35 * z / half)
+    sc = FloorScene(albedo, (1, 1, 1), metalness=1.0, roughness=rough, env=env, half=half, corner_normal=lean)
+    sc.camera.position[:] = (0.5, 4.0, -3.5)
+    sc.camera.target[:] = (0.0, 0.0, 0.3)
+    sc.camera.up[:] = (0.0, 1.0, 0.0)
+    sc.camera.fov_deg = 60.0
+    d = primary_directions(sc.camera, *MIRROR_RES)
+    pos = np.array(list(sc.camera.position), dtype=np.float64)
+    t = -pos[1] / d[..., 1]
+    x, z = pos[0] + t * d[..., 0], pos[2] + t * d[..., 2]
+    corner = lambda cx, cz: np.array(lean(cx, cz), dtype=np.float64)
+    n00, n01, n11, n10 = corner(-half, -half), corner(-half, half), corner(half, half), corner(half, -half)
+    upper = z >= x                                                      # triangle 0: (-h,-h) (-h,h) (h,h); 1: (-h,-h) (h,h) (h,-h)
+    bx = np.where(upper, (z - x) / (2 * half), (z + half) / (2 * half))[..., None]
+    by = np.where(upper, (x + half) / (2 * half), (x - z) / (2 * half))[..., None]
+    n1 = np.where(upper[..., None], n01, n11)
+    n2 = np.where(upper[..., None], n11, n10)
+    N = bx * n1 + by * n2 + (1.0 - bx - by) * n00
+    N /= np.linalg.norm(N, axis=-1, keepdims=True)
+    c = -(d * N).sum(-1, keepdims=True)
+    r = d + 2.0 * c * N
+    sure = (d[..., 1] < 0) & (np.maximum(np.abs(x), np.abs(z)) < half - 1e-3) & (np.abs(z - x) > 1e-3) & (c[..., 0] > 0.05) & (r[..., 1] > 0.05)
+    c = np.clip(c, 1e-6, 1.0)
+    k = rough / 2.0
+    expect = grade((albedo + (1.0 - albedo) * (1.0 - c) ** 5) * (c / (c * (1.0 - k) + k)) ** 2
+                   * env.reshape(-1, 3)[environment_texels(r, env_w, env_h)])
+    assert sure.mean() > 0.2
+    return sc, expect, sure
+
+
+def test_interpolated_normals_on_a_mirror_floor(torch_first):
+    sc, expect, sure = bumpy_mirror_floor()
+    dev = ptamd.DeviceScene(sc.desc_ptr)
+    try:
+        img, _ = dev.render(sc.camera, ptamd.make_params(*MIRROR_RES, spp=1, max_bounces=2))
+    finally:
+        dev.close()
+    check_near_mirror(img, expect, sure)

@@ -7,7 +7,7 @@ import pytest
 
 import oracle_binding as ob
 import ptamd
-from test_gpu_analytic import (LOBE_CASES, LOBE_RES, LOBE_SPP, lobe_scene, MIRROR_RES, MODEL_RES, SKY_RES, SKY_VIEWS, TEX_RES, FloorScene, check_near_mirror, grade,
+from test_gpu_analytic import (bumpy_mirror_floor, LOBE_CASES, LOBE_RES, LOBE_SPP, lobe_scene, MIRROR_RES, MODEL_RES, SKY_RES, SKY_VIEWS, TEX_RES, FloorScene, check_near_mirror, grade,
                                near_mirror_floor, placed_floor, sky_view, textured_floor)
 
 
@@ -82,3 +82,11 @@ def test_sampled_mean_is_the_integral_of_the_lobe_oracle(metalness, roughness):
     acc, _ = ob.accumulate(sc, ptamd.make_params(*LOBE_RES, spp=LOBE_SPP, max_bounces=2), seed_mode=ptamd.SEED_REFERENCE_GPU, threads=4)
     got = acc[..., :3].sum(axis=(0, 1)).astype(np.float64) / float(acc[..., 3].sum())
     assert np.abs(got / expect - 1.0).max() < 0.01, got / expect
+
+
+def test_interpolated_normals_on_a_mirror_floor_oracle():
+    """Barycentric order of the per-corner normals (geometry.cpp:69-87 with Moeller-Trumbore's u, v) through the
+    reflection they cause."""
+    sc, expect, sure = bumpy_mirror_floor()
+    img, _ = ob.render(sc, ptamd.make_params(*MIRROR_RES, spp=1, max_bounces=2), seed_mode=ptamd.SEED_REFERENCE_GPU, threads=2)
+    check_near_mirror(img, expect, sure)
