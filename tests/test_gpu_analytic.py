@@ -512,3 +512,64 @@ def test_interpolated_normals_on_a_mirror_floor(torch_first):
     finally:
         dev.close()
     check_near_mirror(img, expect, sure)
+
+
+class BoxScene(FloorScene):
+    """A closed cube [-1, 1]^3 around the camera: twelve triangles in one BLAS leaf under one TLAS leaf."""
+
+    def __init__(self, albedo, emissive, sky):
+        super().__init__(albedo, sky, emissive=emissive)
+        corners = lambda axis, side: [tuple(side if k == axis else (a if k == (axis + 1) % 3 else b) for k in range(3))
+                                      for a, b in ((-1.0, -1.0), (1.0, -1.0), (1.0, 1.0), (-1.0, 1.0))]
+        self.tris = (ptamd.Triangle * 12)()
+        normals = []
+        i = 0
+        for axis in range(3):
+            for side in (-1.0, 1.0):
+                q = corners(axis, side)
+                for tri in ((q[0], q[1], q[2]), (q[0], q[2], q[3])):
+                    self.tris[i].v0[:], self.tris[i].v1[:], self.tris[i].v2[:] = tri
+                    normals += [side if k == axis else 0.0 for k in range(3)]
+                    i += 1
+        self.face_normals = (C.c_float * 36)(*normals)
+        for n, cnt in ((self.tlas[0], 1), (self.blas[0], 12)):
+            n.aabb_min[:] = (-1.0, -1.0, -1.0)
+            n.aabb_max[:] = (1.0, 1.0, 1.0)
+            n.left_first, n.count = 0, cnt
+        self.geom[0].tri_count = 12
+        d = self.desc
+        d.triangles, d.triangle_total = self.tris, 12
+        d.face_normals, d.face_normal_total = self.face_normals, 12
+        self.camera.position[:] = (0.2, -0.1, 0.3)
+        self.camera.target[:] = (0.9, 0.55, -0.7)
+        self.camera.up[:] = (0.0, 1.0, 0.0)
+        self.camera.fov_deg = 100.0
+
+
+FURNACE = ((0.8, 0.6, 0.9), (0.1, 0.3, 0.05), (7.0, 7.0, 7.0))          # albedo, emissive, a sky nobody may see
+
+
+def check_furnace(render, measure=None):
+    """Inside a closed box no path ever misses: after B bounces the loop ends and returns the throughput
+    (gpuRender.cu:27-29), the product of (albedo + emissive) over B hits, whatever was sampled: grade((a + e)^B).
+    Checks the bounce loop, its count, and that a bounce leaves from the near side of the wall (p + 1e-4 N with N
+    turned against the ray, gpuRender.cu:52-55 and :109)."""
+    a, e = np.array(FURNACE[0]), np.array(FURNACE[1])
+    for bounces, spp in ((1, 1), (2, 3), (4, 2), (6, 4)):
+        p = ptamd.make_params(120, 80, spp=spp, max_bounces=bounces)
+        img = render(p)
+        err = np.abs(img - grade((a + e) ** bounces).astype(np.float32)).max(axis=2)
+        # Moeller-Trumbore is not watertight: a ray through an edge of the cube may slip out and see the sky
+        assert (err > 2e-6).sum() <= 2, (bounces, int((err > 2e-6).sum()), float(err.max()))
+        if measure is not None:
+            m = measure(p)
+            assert abs(int(m.hits) - 120 * 80 * spp * bounces) <= 2 * bounces and m.misses <= 2
+
+
+def test_furnace_box(torch_first):
+    sc = BoxScene(*FURNACE)
+    dev = ptamd.DeviceScene(sc.desc_ptr)
+    try:
+        check_furnace(lambda p: dev.render(sc.camera, p)[0], lambda p: dev.measure(sc.camera, p))
+    finally:
+        dev.close()

@@ -7,7 +7,7 @@ import pytest
 
 import oracle_binding as ob
 import ptamd
-from test_gpu_analytic import (bumpy_mirror_floor, LOBE_CASES, LOBE_RES, LOBE_SPP, lobe_scene, MIRROR_RES, MODEL_RES, SKY_RES, SKY_VIEWS, TEX_RES, FloorScene, check_near_mirror, grade,
+from test_gpu_analytic import (BoxScene, bumpy_mirror_floor, check_furnace, FURNACE, LOBE_CASES, LOBE_RES, LOBE_SPP, lobe_scene, MIRROR_RES, MODEL_RES, SKY_RES, SKY_VIEWS, TEX_RES, FloorScene, check_near_mirror, grade,
                                near_mirror_floor, placed_floor, sky_view, textured_floor)
 
 
@@ -90,3 +90,15 @@ def test_interpolated_normals_on_a_mirror_floor_oracle():
     sc, expect, sure = bumpy_mirror_floor()
     img, _ = ob.render(sc, ptamd.make_params(*MIRROR_RES, spp=1, max_bounces=2), seed_mode=ptamd.SEED_REFERENCE_GPU, threads=2)
     check_near_mirror(img, expect, sure)
+
+
+def test_furnace_box_oracle():
+    sc = BoxScene(*FURNACE)
+    stats = {}
+
+    def render(p):
+        img, st = ob.render(sc, p, seed_mode=ptamd.SEED_REFERENCE_GPU, threads=2)
+        stats["st"] = st
+        return img
+
+    check_furnace(render, lambda p: stats["st"])
