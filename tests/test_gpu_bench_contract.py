@@ -35,3 +35,28 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     # value = rays of the timed steps / wall time
     assert abs(j["value"] - j["config"]["rays_per_step"] / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * j["value"]
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, one rank per GPU), rehearsed with
+    both ranks on this box's one GPU and gloo in place of RCCL: the samples of the frame are split over the ranks
+    (strong scaling), each renders its share with its own RNG streams, the accumulation buffers are summed on rank 0,
+    rank 0 prints the one line, whose rays are those of the whole frame."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PTX_BENCH_CPU_BUDGET="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--spp", "6",
+           "--rehearse-on-one-gpu"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+    # 6 spp over two ranks: 1500 * 800 * 6 paths in all, between one and six rays each
+    paths = 1500 * 800 * 6
+    assert paths <= j["config"]["rays_per_step"] <= 6 * paths
+    assert abs(j["value"] - j["config"]["rays_per_step"] / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * j["value"]
