@@ -25,7 +25,7 @@ st = d.measure(s.camera, p)
 assert lib.ptx_debug_wave_profile(buf) == 0
 # radiance_kernel.hpp (wide layout, default) / kernels.hpp pathKernel (PTX_RAD_LEGACY=1 or PTX_WIDE=0)
 legacy = os.environ.get("PTX_RAD_LEGACY") == "1" or os.environ.get("PTX_WIDE") == "0"
-names = (["loop", "shade", "step", "exit", "enter", "tri", "node", "node-exact"] if legacy else
+names = (["loop", "shade", "step", "leaving", "enter", "tri", "node", "node-exact"] if legacy else
          ["loop", "shade", "node", "tri", "enter", "tail only", "deep stack", "exit (in tail)"])
 iters = buf[0]
 out = {"rays": st.rays, "node_steps": st.node_steps, "tri_tests": st.tri_tests, "inst_entries": st.inst_entries, "render_s": st.render_s}
