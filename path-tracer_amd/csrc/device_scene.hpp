@@ -109,6 +109,7 @@ struct DeviceScene {
   uint32_t tlasRootRefWide;  // the TLAS root in the wide layout
   uint32_t tlasNodeEnd[2];   // internal-node references below this belong to the TLAS ([0] NodePair, [1] WideNode index)
   uint32_t envWidth, envHeight;
+  float envHeightF;  // (float)envHeight, converted on the host: a uniform operand, not a per-lane register
 };
 
 // Per-frame constants, computed once on the host (the reference recomputes viewMatrix, tan(fov) and
@@ -130,6 +131,7 @@ struct FrameConstants {
   uint32_t subStreams;          // RNG streams per pixel in this launch (>= 1), each a separate work item
   uint32_t sppBase, sppExtra;   // stream k renders sppBase + (k < sppExtra) samples
   uint32_t widthMul, widthShift;  // n / width for n < 2^24: umulhi(n << 8, widthMul) >> widthShift
+  uint32_t bandMul, bandShift;    // the same for n / (8 * width)
   double invPixels;               // 1.0 / (width * height)
 };
 

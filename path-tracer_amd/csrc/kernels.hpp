@@ -42,11 +42,14 @@
 namespace ptx {
 
 constexpr uint32_t kBlockThreads = 256;  // 4 waves
-#ifndef PTX_LDS_STACK
-#define PTX_LDS_STACK 26
+#ifndef PTX_PARK
+#define PTX_PARK 1   // traversal-only lane state waits in memory during the shading phase (0: stays in registers; then 5 waves/SIMD)
 #endif
 #ifndef PTX_MIN_WAVES
-#define PTX_MIN_WAVES 5
+#define PTX_MIN_WAVES (PTX_PARK ? 6 : 5)  // waves per SIMD the register budget is cut for: 80 / 96 VGPRs
+#endif
+#ifndef PTX_LDS_STACK
+#define PTX_LDS_STACK (PTX_PARK ? 23 : 26)  // with the item's running sum (3 dwords per lane): 26 KB per block either way
 #endif
 constexpr uint32_t kLdsStack = PTX_LDS_STACK;  // stack entries per lane kept in LDS (1 KB per entry per block)
 // Tunables (see DESIGN.md "Scheduling inside a wave").
@@ -95,6 +98,8 @@ __device__ unsigned long long gWaveProfile[32];
 __device__ unsigned int gVisitHist[1u << 20];  // node steps per pair index (profiling builds only)
 #endif
 
+constexpr uint32_t kParkRegs = 16u;                       // dwords of traversal state parked during the shading phase
+constexpr uint32_t kParkSlots = PTX_PARK ? kParkRegs + 1u : 0u;  // entries of the global park area: those, and the bounce counter
 constexpr int kModeCounts = 0;    // `-a`: gpuRender.cu:146-150
 constexpr int kModeRadiance = 1;  // gpuRender.cu:132-169
 
@@ -139,7 +144,7 @@ __device__ __forceinline__ void stackWrite(const StackMem& m, uint32_t slot, uin
 // any image size, with no padding items.
 __device__ __forceinline__ void workPixel(const FrameConstants& fc, uint32_t w, uint32_t& x, uint32_t& y) {
   const uint32_t bandItems = fc.width * 8u;
-  const uint32_t band = w / bandItems;
+  const uint32_t band = __umulhi(w << 8, fc.bandMul) >> fc.bandShift;  // w / bandItems, w < 2^24 (see divByWidth)
   const uint32_t r = w - band * bandItems;
   const uint32_t rows = min(8u, fc.height - band * 8u);
   const uint32_t cx = r / rows;
@@ -160,10 +165,18 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
                                                             uint32_t* stackOverflow) {
   constexpr bool kOneRay = MODE == kModeCounts;  // heat map: one primary ray per pixel
   __shared__ uint32_t sStack[kLdsStack * kBlockThreads];
+#if PTX_PARK
+  // the work item's running sum is touched when a path ends and when the item is written: LDS, not three registers
+  __shared__ float sSum[3 * kBlockThreads];
+  float* const sumLds = sSum + threadIdx.x;
+#endif
   StackMem stk;
   stk.lds = sStack + threadIdx.x;
-  stk.overflow = stackOverflow + (blockIdx.x * kBlockThreads + threadIdx.x);
   stk.stride = gridDim.x * kBlockThreads;
+  // the first kParkSlots entries of the area are the park slots of the shading phase (PTX_PARK)
+  uint32_t* const parkGlobal = stackOverflow + (blockIdx.x * kBlockThreads + threadIdx.x);
+  stk.overflow = parkGlobal + (size_t)kParkSlots * stk.stride;
+  (void)parkGlobal;
   uint32_t sp = 1;
 
   const uint32_t nPixels = fc.width * fc.height;
@@ -207,8 +220,38 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
     PTX_PROF(0, ref != kRefIdle);
     if (nWaiting >= PTX_SHADE_THRESHOLD || nWaiting * 4u >= nLive) {
       PTX_PROF(1, waiting);
+#if PTX_PARK
+      // The shading phase is where the register pressure peaks, and the lanes that do not shade only carry their
+      // traversal state through it: it waits in the stack slots above the lane's top (free by construction; the
+      // overflow area is sized for them), so the registers are free for the shading arithmetic.
+      // wave-uniform: in LDS when every lane has kParkSlots free entries above its top, else in the global park area
+      const bool parkLds = !__any(sp + kParkRegs > kLdsStack);
+      if (MODE == kModeRadiance) {
+        const uint32_t pv[16] = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(d.x),
+                                         __float_as_uint(d.y), __float_as_uint(d.z), __float_as_uint(inv.x), __float_as_uint(inv.y),
+                                         __float_as_uint(inv.z), __float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v),
+                                         hit.tri, hit.inst, tlasLeaf, curInst};
+        if (parkLds) {
+#pragma unroll
+          for (uint32_t i = 0; i < kParkRegs; i++) stk.lds[(sp + i) * kBlockThreads] = pv[i];
+        } else {
+          uint32_t* pg = parkGlobal;
+          asm volatile("" : "+v"(pg));  // the addresses are computed here, not kept in registers across the loop
+#pragma unroll
+          for (uint32_t i = 0; i < kParkRegs; i++) { *pg = pv[i]; pg += stk.stride; }
+        }
+      }
+#endif
       if (waiting) {
         bool pathEnded = true;
+#if PTX_PARK
+        // The bounce counter is touched here and nowhere else: it lives in the park area between shading phases
+        // (read now, needed a thousand instructions later; written back at the launch of the next segment).
+        uint32_t* bounceSlot = parkGlobal;
+        asm volatile("" : "+v"(bounceSlot));
+        bounceSlot += (size_t)kParkRegs * stk.stride;
+        if (MODE == kModeRadiance && havePixel) bounce = *bounceSlot;
+#endif
         if (havePixel) {
           if (STATS) {
             nRays++;
@@ -230,7 +273,11 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
           }
           PTX_MARK("S_AFTER");
           if (MODE == kModeRadiance && pathEnded) {
+#if PTX_PARK
+            sumLds[0] += col.x; sumLds[kBlockThreads] += col.y; sumLds[2 * kBlockThreads] += col.z;
+#else
             sum += col;
+#endif
             sample--;
           }
         }
@@ -243,6 +290,9 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
               const uint32_t p = pix & 0x00FFFFFFu, k = pix >> 24;
               // plane k of the accumulation buffer: (sum, samples) of stream k
               const uint32_t n = fc.sppBase + (k < fc.sppExtra ? 1u : 0u);
+#if PTX_PARK
+              sum = vec3(sumLds[0], sumLds[kBlockThreads], sumLds[2 * kBlockThreads]);
+#endif
               reinterpret_cast<float4*>(outRaw)[(size_t)k * nPixels + p] = make_float4(sum.x, sum.y, sum.z, (float)n);
             }
             const uint32_t w = atomicAdd(workCounter, 1u);  // aggregated per wave by the compiler
@@ -270,6 +320,9 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
             const uint32_t p = y * fc.width + x;
             pix = p | (k << 24);
             sum = vec3(0.0f);
+#if PTX_PARK
+            sumLds[0] = 0.0f; sumLds[kBlockThreads] = 0.0f; sumLds[2 * kBlockThreads] = 0.0f;
+#endif
             rng = fc.seedBase + p + k * 0x9E3779B9u;  // gpuRender.cu:130 (+ stream offset)
             havePixel = true;
             sample = kOneRay ? 1u : fc.sppBase + (k < fc.sppExtra ? 1u : 0u);
@@ -283,6 +336,9 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
               }
             } else if (fc.maxBounces == 0u) {
               sum = vec3((float)sample);  // no segment is traced: every path returns white (gpuRender.cu:27-29)
+#if PTX_PARK
+              sumLds[0] = sum.x; sumLds[kBlockThreads] = sum.y; sumLds[2 * kBlockThreads] = sum.z;
+#endif
               sample = 0u;
             }
           }
@@ -308,11 +364,16 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
           // ---- launch the segment: Scene::intersect starts at the TLAS root ----
           reciprocalDir(wd, winv, wZeroDir);
           zeroDir = wZeroDir;
-          o = wo; d = wd; inv = winv;
-          hit.t = FLT_MAX; hit.u = 0.0f; hit.v = 0.0f; hit.tri = 0xFFFFFFFFu; hit.inst = 0xFFFFFFFFu;
+          if (!(PTX_PARK && MODE == kModeRadiance)) {
+            o = wo; d = wd; inv = winv;
+            hit.t = FLT_MAX; hit.u = 0.0f; hit.v = 0.0f; hit.tri = 0xFFFFFFFFu; hit.inst = 0xFFFFFFFFu;
+            tlasLeaf = 0u;
+          }
           count = 0u;
-          tlasLeaf = 0u;
           inInst = false;
+#if PTX_PARK
+          if (MODE == kModeRadiance) *bounceSlot = bounce;
+#endif
           stk.lds[0] = kRefDone;  // slot 0: bottom-of-stack marker
           sp = 1u;
           ref = WIDE ? sc.tlasRootRefWide : sc.tlasRootRef;
@@ -320,6 +381,33 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
           ref = kRefIdle;
         }
       }
+#if PTX_PARK
+      if (MODE == kModeRadiance) {
+        // a lane that shaded starts its new segment (world space, no hit yet); the others get their state back
+        uint32_t pv[16] = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z),
+                           __float_as_uint(inv.x), __float_as_uint(inv.y), __float_as_uint(inv.z), __float_as_uint(hit.t), __float_as_uint(hit.u),
+                           __float_as_uint(hit.v), hit.tri, hit.inst, tlasLeaf, curInst};  // what is not parked stays where it is
+        if (parkLds) {
+#pragma unroll
+          for (uint32_t i = 0; i < kParkRegs; i++) pv[i] = stk.lds[(sp + i) * kBlockThreads];
+        } else {
+          const uint32_t* pg = parkGlobal;
+          asm volatile("" : "+v"(pg));
+#pragma unroll
+          for (uint32_t i = 0; i < kParkRegs; i++) { pv[i] = *pg; pg += stk.stride; }
+        }
+        o.x = waiting ? wo.x : __uint_as_float(pv[0]); o.y = waiting ? wo.y : __uint_as_float(pv[1]); o.z = waiting ? wo.z : __uint_as_float(pv[2]);
+        d.x = waiting ? wd.x : __uint_as_float(pv[3]); d.y = waiting ? wd.y : __uint_as_float(pv[4]); d.z = waiting ? wd.z : __uint_as_float(pv[5]);
+        inv.x = waiting ? winv.x : __uint_as_float(pv[6]); inv.y = waiting ? winv.y : __uint_as_float(pv[7]); inv.z = waiting ? winv.z : __uint_as_float(pv[8]);
+        hit.t = waiting ? FLT_MAX : __uint_as_float(pv[9]);
+        hit.u = waiting ? 0.0f : __uint_as_float(pv[10]);
+        hit.v = waiting ? 0.0f : __uint_as_float(pv[11]);
+        hit.tri = waiting ? 0xFFFFFFFFu : pv[12];
+        hit.inst = waiting ? 0xFFFFFFFFu : pv[13];
+        tlasLeaf = waiting ? 0u : pv[14];
+        curInst = pv[15];
+      }
+#endif
     }
 
     PTX_STAMP(0);  // shading phase (and the loop-top checks)

@@ -337,6 +337,11 @@ int makeFrame(const ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, 
     while ((1u << sh) < prm->width) sh++;  // width <= 2^24
     fc.widthShift = sh;
     fc.widthMul = (uint32_t)((((uint64_t)1 << (24 + sh)) + prm->width - 1u) / prm->width);  // <= 2^25
+    const uint64_t band = 8ull * prm->width;  // <= 2^27
+    sh = 0;
+    while ((1ull << sh) < band) sh++;
+    fc.bandShift = sh;
+    fc.bandMul = (uint32_t)((((uint64_t)1 << (24 + sh)) + band - 1u) / band);
   }
   fc.seedBase = 1023u;
   // stream id of this call's k-th stream = part_index * sub_streams + k with the REQUESTED sub_streams: a part whose
@@ -409,7 +414,7 @@ int planLaunch(ptx_scene* s, K kernel, const FrameConstants& fc, bool wide, uint
   const size_t deepEntries = bound > ldsStack ? bound - ldsStack : 0u;  // entries beyond the kernel's LDS part
   plan.blocks = blocks;
   plan.wide = wide;
-  plan.ovfBytes = (deepEntries ? deepEntries : 1u) * (size_t)raysPerLane * blocks * kBlockThreads * sizeof(uint32_t);
+  plan.ovfBytes = ((deepEntries ? deepEntries : 1u) + kParkSlots) * (size_t)raysPerLane * blocks * kBlockThreads * sizeof(uint32_t);
   return PTX_OK;
 }
 
@@ -793,6 +798,7 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
   s->wideStackBound = wideStackBound;
   D.envWidth = d->env_width;
   D.envHeight = d->env_height;
+  D.envHeightF = (float)d->env_height;
   s->tlasDepth = tlas.depth;
   s->blasDepth = blasDepth;
   // set-up for the no-allocation entry point: this device's address of the static scratch array, and

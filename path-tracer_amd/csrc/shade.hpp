@@ -30,7 +30,7 @@ __device__ __forceinline__ vec3 environmentLookup(const DeviceScene& sc, const F
   const double invpi = 1.0f / 3.14159265358979323846;
   const uint32_t W = sc.envWidth, H = sc.envHeight;
   const uint32_t u = (uint32_t)(W * (atan2f(sampleDir.z, sampleDir.x) * inv2pi + 0.5f));
-  const uint32_t v = (uint32_t)((float)H * acosf(sampleDir.y) * invpi);
+  const uint32_t v = (uint32_t)(sc.envHeightF * acosf(sampleDir.y) * invpi);  // (float)H * ...
   const uint32_t idx = pt::gmin(u + v * W, (W * H) - 1u);
   return f4xyz(sc.environment[idx]);
 }
