@@ -244,13 +244,14 @@ int ptx_render_counts_multi(ptx_scene* const* scenes, uint32_t count, const ptx_
  * counter, the traversal-stack overflow area, and (sub_streams > 1) the per-stream accumulation planes
  * -- comes from ONE static array of PTX_NOALLOC_SCRATCH_BYTES that the library holds on every GPU it
  * runs on until the process ends; the call makes no hipMalloc / hipFree.  A launch that needs more
- * (planes = sub_streams * width * height * 16 bytes; the overflow area is at most 76 MB for the preset scenes:
- * (stack bound 84 - 26) * 4 bytes per lane of the 327,680-lane persistent grid, scene 1 on the wide layout)
+ * (planes = sub_streams * width * height * 16 bytes; the stack overflow and park area is at most 123 MB for the
+ * preset scenes: (stack bound 84 - 23 entries in LDS + 17 park slots) * 4 bytes per lane of the 393,216-lane
+ * persistent grid, scene 1 on the wide layout)
  * fails with PTX_ELIMIT and a message that names the numbers.  All calls on one GPU share that GPU's
  * array, whatever the scene handle: calls that overlap on one GPU (two streams, two threads) race;
  * calls ordered on one stream do not.  Requires a handle from ptx_create on the same device (that is
  * where the array's device address is resolved). */
-#define PTX_NOALLOC_SCRATCH_BYTES (128u << 20)
+#define PTX_NOALLOC_SCRATCH_BYTES (256u << 20)
 int ptx_accumulate_device_noalloc(ptx_scene* scene, const ptx_camera* camera, const ptx_params* params,
                                   float* d_accum, void* hip_stream);
 

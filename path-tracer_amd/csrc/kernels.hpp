@@ -45,6 +45,9 @@ constexpr uint32_t kBlockThreads = 256;  // 4 waves
 #ifndef PTX_PARK
 #define PTX_PARK 1   // traversal-only lane state waits in memory during the shading phase (0: stays in registers; then 5 waves/SIMD)
 #endif
+#ifndef PTX_SHADE_SHARE
+#define PTX_SHADE_SHARE 4u   // ... or when one live lane in this many waits (the tail of the frame)
+#endif
 #ifndef PTX_MIN_WAVES
 #define PTX_MIN_WAVES (PTX_PARK ? 6 : 5)  // waves per SIMD the register budget is cut for: 80 / 96 VGPRs
 #endif
@@ -98,7 +101,7 @@ __device__ unsigned long long gWaveProfile[32];
 __device__ unsigned int gVisitHist[1u << 20];  // node steps per pair index (profiling builds only)
 #endif
 
-constexpr uint32_t kParkRegs = 16u;                       // dwords of traversal state parked during the shading phase
+constexpr uint32_t kParkRegs = 16u;                      // dwords of traversal state parked during the shading phase
 constexpr uint32_t kParkSlots = PTX_PARK ? kParkRegs + 1u : 0u;  // entries of the global park area: those, and the bounce counter
 constexpr int kModeCounts = 0;    // `-a`: gpuRender.cu:146-150
 constexpr int kModeRadiance = 1;  // gpuRender.cu:132-169
@@ -218,7 +221,10 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
     const uint32_t nLive = 64u - (uint32_t)__popcll(__ballot(ref == kRefIdle));
     if (nLive == 0u) break;
     PTX_PROF(0, ref != kRefIdle);
-    if (nWaiting >= PTX_SHADE_THRESHOLD || nWaiting * 4u >= nLive) {
+    // one ray per pixel (`-a`): the phase is short and the frame is all tail, so it pays to wait for half of the
+    // live lanes (1.65 -> 1.29 ms at 1500x800 on scene 1); radiance: 16 lanes or a quarter (12: +3 %, 32 / half: +3.5 %)
+    constexpr uint32_t kShadeLanes = kOneRay ? 32u : PTX_SHADE_THRESHOLD, kShadeShare = kOneRay ? 2u : PTX_SHADE_SHARE;
+    if (nWaiting >= kShadeLanes || nWaiting * kShadeShare >= nLive) {
       PTX_PROF(1, waiting);
 #if PTX_PARK
       // The shading phase is where the register pressure peaks, and the lanes that do not shade only carry their
@@ -384,9 +390,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
 #if PTX_PARK
       if (MODE == kModeRadiance) {
         // a lane that shaded starts its new segment (world space, no hit yet); the others get their state back
-        uint32_t pv[16] = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z),
-                           __float_as_uint(inv.x), __float_as_uint(inv.y), __float_as_uint(inv.z), __float_as_uint(hit.t), __float_as_uint(hit.u),
-                           __float_as_uint(hit.v), hit.tri, hit.inst, tlasLeaf, curInst};  // what is not parked stays where it is
+        uint32_t pv[kParkRegs];
         if (parkLds) {
 #pragma unroll
           for (uint32_t i = 0; i < kParkRegs; i++) pv[i] = stk.lds[(sp + i) * kBlockThreads];
@@ -405,7 +409,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
         hit.tri = waiting ? 0xFFFFFFFFu : pv[12];
         hit.inst = waiting ? 0xFFFFFFFFu : pv[13];
         tlasLeaf = waiting ? 0u : pv[14];
-        curInst = pv[15];
+        curInst = waiting ? 0u : pv[15];
       }
 #endif
     }

@@ -49,7 +49,7 @@ def test_noalloc_equals_the_allocating_entry_point(gpu_scenes):
 def test_noalloc_refuses_what_does_not_fit(gpu_scenes):
     torch = pytest.importorskip("torch")
     hosts, devs = gpu_scenes
-    # planes: 25 streams x 1500 x 800 x 16 B = 480 MB > the 128 MiB array
+    # planes: 25 streams x 1500 x 800 x 16 B = 480 MB > the 256 MiB array
     p = ptamd.make_params(1500, 800, spp=100, max_bounces=6, seed_mode=ptamd.SEED_STREAM, sub_streams=25)
     buf = torch.zeros((800, 1500, 4), dtype=torch.float32, device="cuda")
     with pytest.raises(ptamd.BackendError, match="scratch"):
