@@ -162,8 +162,34 @@ __device__ __forceinline__ uint32_t divByWidth(const FrameConstants& fc, uint32_
   return __umulhi(n << 8, fc.widthMul) >> fc.widthShift;
 }
 
+#ifndef PTX_RELOAD_FRAME
+#define PTX_RELOAD_FRAME 1  // the frame constants are read from the kernel-argument segment at every shading phase
+#endif
+// The kernel arguments as the hardware lays them out (HIP: in order, each at its natural alignment).
+struct PathKernelArgs {
+  DeviceScene sc;
+  FrameConstants fc;
+};
+// A copy of a kernel argument made by scalar loads from the kernel-argument segment where it is called, instead of
+// SGPRs held from the kernel's entry: the frame constants (50 dwords) are used in the shading phase only, and holding
+// them through the traversal loop made the compiler keep 42 SGPRs in the lanes of a VGPR (v_readlane / v_writelane
+// around every use: 126 of them in the hit shading alone).
+template <typename T>
+__device__ __forceinline__ T loadKernelArgument(uint32_t byteOffset) {
+  typedef const uint32_t __attribute__((address_space(4))) * KernargWords;
+  KernargWords k = (KernargWords)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(k));  // not hoisted out of the loop
+  T out;
+  uint32_t* o = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+  for (uint32_t i = 0; i < sizeof(T) / 4u; i++) o[i] = k[byteOffset / 4u + i];
+  return out;
+}
+
+// The register budget: 6 waves/SIMD (80 VGPRs) for the shipped radiance kernel and the heat map; the instrumented
+// variants and the binary-layout fallback of the radiance path carry more state and keep 5 (96 VGPRs): no scratch anywhere.
 template <int MODE, bool STATS, bool WIDE>
-__global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(DeviceScene sc, FrameConstants fc, uint32_t* workCounter,
+__global__ void __launch_bounds__(kBlockThreads, (WIDE && !STATS) || MODE == kModeCounts ? PTX_MIN_WAVES : 5) pathKernel(DeviceScene sc, FrameConstants fcArg, uint32_t* workCounter,
                                                             void* __restrict__ outRaw, DeviceStats* stats,
                                                             uint32_t* stackOverflow) {
   constexpr bool kOneRay = MODE == kModeCounts;  // heat map: one primary ray per pixel
@@ -182,9 +208,14 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
   (void)parkGlobal;
   uint32_t sp = 1;
 
+#if !PTX_RELOAD_FRAME
+  const FrameConstants& fc = fcArg;
   const uint32_t nPixels = fc.width * fc.height;
   const uint32_t totalWork = nPixels * fc.subStreams;  // checked on the host to fit 32 bits
   const vec3 camPos(fc.camPos[0], fc.camPos[1], fc.camPos[2]);
+#else
+  (void)fcArg;
+#endif
 
   // ---- lane state ----
   uint32_t ref = kRefDone;   // what the lane does next (see the table above)
@@ -250,6 +281,12 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_MIN_WAVES) pathKernel(Devic
 #endif
       if (waiting) {
         bool pathEnded = true;
+#if PTX_RELOAD_FRAME
+        const FrameConstants fc = loadKernelArgument<FrameConstants>((uint32_t)offsetof(PathKernelArgs, fc));
+        const uint32_t nPixels = fc.width * fc.height;
+        const uint32_t totalWork = nPixels * fc.subStreams;  // checked on the host to fit 32 bits
+        const vec3 camPos(fc.camPos[0], fc.camPos[1], fc.camPos[2]);
+#endif
 #if PTX_PARK
         // The bounce counter is touched here and nowhere else: it lives in the park area between shading phases
         // (read now, needed a thousand instructions later; written back at the launch of the next segment).
