@@ -28,6 +28,13 @@
 // flight, a wave is never held hostage by its slowest path, and an image with 100x cost differences
 // between pixels (scene 1) load-balances through the counter.
 //
+// Registers follow the phases.  The shading phase is where the register pressure peaks, and the lanes that do not
+// shade only carry their traversal state through it, so that state (ray, hit record, TLAS-leaf rest, instance:
+// 16 dwords) is stored before the phase and read back after it; the bounce counter, touched in the phase only,
+// stays in the same park area between phases; the work item's running sum lives in LDS; the frame constants are
+// re-read from the kernel-argument segment by scalar loads in the phase instead of occupying SGPRs through the
+// loop.  That is what lets the radiance kernel run at 6 waves per SIMD (80 VGPRs) with no scratch.
+//
 // `-a`: per-ray visit order, ray.t at every slab test and every rounding are those of the reference's
 // nested traversal (intersection.hpp:99-233), so the counts are bit-exact against the CPU path.
 // Radiance draws the same random numbers as the reference's GPU kernel and finds the same hits through
