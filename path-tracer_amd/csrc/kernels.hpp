@@ -108,6 +108,7 @@ __device__ unsigned long long gWaveProfile[32];
 __device__ unsigned int gVisitHist[1u << 20];  // node steps per pair index (profiling builds only)
 #endif
 
+typedef uint32_t __attribute__((address_space(1))) * GlobalWords;  // a pointer the compiler knows to be global memory
 constexpr uint32_t kParkRegs = 16u;                      // dwords of traversal state parked during the shading phase
 constexpr uint32_t kParkSlots = PTX_PARK ? kParkRegs + 1u : 0u;  // entries of the global park area: those, and the bounce counter
 constexpr int kModeCounts = 0;    // `-a`: gpuRender.cu:146-150
@@ -279,8 +280,8 @@ __global__ void __launch_bounds__(kBlockThreads, (WIDE && !STATS) || MODE == kMo
 #pragma unroll
           for (uint32_t i = 0; i < kParkRegs; i++) stk.lds[(sp + i) * kBlockThreads] = pv[i];
         } else {
-          uint32_t* pg = parkGlobal;
-          asm volatile("" : "+v"(pg));  // the addresses are computed here, not kept in registers across the loop
+          GlobalWords pg = (GlobalWords)parkGlobal;  // global, not flat: the asm hides where the pointer came from
+          asm volatile("" : "+v"(pg));            // the addresses are computed here, not kept in registers across the loop
 #pragma unroll
           for (uint32_t i = 0; i < kParkRegs; i++) { *pg = pv[i]; pg += stk.stride; }
         }
@@ -297,7 +298,7 @@ __global__ void __launch_bounds__(kBlockThreads, (WIDE && !STATS) || MODE == kMo
 #if PTX_PARK
         // The bounce counter is touched here and nowhere else: it lives in the park area between shading phases
         // (read now, needed a thousand instructions later; written back at the launch of the next segment).
-        uint32_t* bounceSlot = parkGlobal;
+        GlobalWords bounceSlot = (GlobalWords)parkGlobal;
         asm volatile("" : "+v"(bounceSlot));
         bounceSlot += (size_t)kParkRegs * stk.stride;
         if (MODE == kModeRadiance && havePixel) bounce = *bounceSlot;
@@ -439,7 +440,7 @@ __global__ void __launch_bounds__(kBlockThreads, (WIDE && !STATS) || MODE == kMo
 #pragma unroll
           for (uint32_t i = 0; i < kParkRegs; i++) pv[i] = stk.lds[(sp + i) * kBlockThreads];
         } else {
-          const uint32_t* pg = parkGlobal;
+          GlobalWords pg = (GlobalWords)parkGlobal;
           asm volatile("" : "+v"(pg));
 #pragma unroll
           for (uint32_t i = 0; i < kParkRegs; i++) { pv[i] = *pg; pg += stk.stride; }
