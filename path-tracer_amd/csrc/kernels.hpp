@@ -267,15 +267,18 @@ __global__ void __launch_bounds__(kBlockThreads, (WIDE && !STATS) || MODE == kMo
       PTX_PROF(1, waiting);
 #if PTX_PARK
       // The shading phase is where the register pressure peaks, and the lanes that do not shade only carry their
-      // traversal state through it: it waits in the stack slots above the lane's top (free by construction; the
-      // overflow area is sized for them), so the registers are free for the shading arithmetic.
-      // wave-uniform: in LDS when every lane has kParkSlots free entries above its top, else in the global park area
+      // traversal state through it: every lane stores it here and picks it up after the phase (a lane that shaded
+      // takes its new segment's values instead), so the registers are free for the shading arithmetic.  Where to:
+      // the LDS stack slots above the lane's top when every lane of the wave has kParkRegs of them free
+      // (wave-uniform; shallow trees), else the lane's column of the global park area.  Stores and loads are
+      // unconditional and the hand-over is a select per value: a conditional version makes the compiler keep
+      // the registers (profiles/r02/park_6waves_ab.txt).
       const bool parkLds = !__any(sp + kParkRegs > kLdsStack);
       if (MODE == kModeRadiance) {
-        const uint32_t pv[16] = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(d.x),
-                                         __float_as_uint(d.y), __float_as_uint(d.z), __float_as_uint(inv.x), __float_as_uint(inv.y),
-                                         __float_as_uint(inv.z), __float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v),
-                                         hit.tri, hit.inst, tlasLeaf, curInst};
+        const uint32_t pv[kParkRegs] = {__float_as_uint(o.x),   __float_as_uint(o.y),   __float_as_uint(o.z),   __float_as_uint(d.x),
+                                        __float_as_uint(d.y),   __float_as_uint(d.z),   __float_as_uint(inv.x), __float_as_uint(inv.y),
+                                        __float_as_uint(inv.z), __float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v),
+                                        hit.tri,                hit.inst,               tlasLeaf,               curInst};
         if (parkLds) {
 #pragma unroll
           for (uint32_t i = 0; i < kParkRegs; i++) stk.lds[(sp + i) * kBlockThreads] = pv[i];
