@@ -58,6 +58,9 @@ constexpr uint32_t kBlockThreads = 256;  // 4 waves
 #ifndef PTX_MIN_WAVES
 #define PTX_MIN_WAVES (PTX_PARK ? 6 : 5)  // waves per SIMD the register budget is cut for: 80 / 96 VGPRs
 #endif
+#ifndef PTX_OTHER_MIN_WAVES
+#define PTX_OTHER_MIN_WAVES 5  // instrumented variants and the binary-layout radiance fallback (profiling builds may ask for 6)
+#endif
 #ifndef PTX_LDS_STACK
 #define PTX_LDS_STACK (PTX_PARK ? 23 : 26)  // with the item's running sum (3 dwords per lane): 26 KB per block either way
 #endif
@@ -197,7 +200,7 @@ __device__ __forceinline__ T loadKernelArgument(uint32_t byteOffset) {
 // The register budget: 6 waves/SIMD (80 VGPRs) for the shipped radiance kernel and the heat map; the instrumented
 // variants and the binary-layout fallback of the radiance path carry more state and keep 5 (96 VGPRs): no scratch anywhere.
 template <int MODE, bool STATS, bool WIDE>
-__global__ void __launch_bounds__(kBlockThreads, (WIDE && !STATS) || MODE == kModeCounts ? PTX_MIN_WAVES : 5) pathKernel(DeviceScene sc, FrameConstants fcArg, uint32_t* workCounter,
+__global__ void __launch_bounds__(kBlockThreads, (WIDE && !STATS) || MODE == kModeCounts ? PTX_MIN_WAVES : PTX_OTHER_MIN_WAVES) pathKernel(DeviceScene sc, FrameConstants fcArg, uint32_t* workCounter,
                                                             void* __restrict__ outRaw, DeviceStats* stats,
                                                             uint32_t* stackOverflow) {
   constexpr bool kOneRay = MODE == kModeCounts;  // heat map: one primary ray per pixel
