@@ -22,6 +22,7 @@
 #ifdef PTX_EXPERIMENT_EXCHANGE  // DESIGN.md section 3, "block exchange": measured slower, kept for A/B builds only
 #include "exchange_kernel.hpp"
 #endif
+#include "queue_kernel.hpp"
 #include "tight_bounds.hpp"
 #include "wide_bvh.hpp"
 
@@ -266,6 +267,9 @@ struct ptx_scene {
   float4* dPlanes = nullptr;  // per-stream accumulation planes of a sub-stream launch
   size_t planeBytes = 0;
   unsigned char* staticScratch = nullptr;  // this device's copy of gNoAllocScratch (resolved in ptx_create)
+  unsigned char* dQueue = nullptr;         // queues and chain records of queueKernel (queue_kernel.hpp), grown on demand
+  size_t queueBytes = 0;
+  bool queueLaunched = false;              // the last radiance launch was a queueKernel: its error word is read at the next synchronisation
   // ptx_render_multi / ptx_render_counts_multi: this handle's own stream and "my part is on the root" event,
   // and (root handle only) the buffer the parts are gathered into
   hipStream_t ownStream = nullptr;
@@ -401,7 +405,8 @@ struct LaunchPlan {
 };
 
 template <typename K>
-int planLaunch(ptx_scene* s, K kernel, const FrameConstants& fc, bool wide, uint32_t ldsStack, uint32_t raysPerLane, LaunchPlan& plan) {
+int planLaunch(ptx_scene* s, K kernel, const FrameConstants& fc, bool wide, uint32_t ldsStack, uint32_t raysPerLane, LaunchPlan& plan,
+               uint32_t parkSlots = kParkSlots) {
   uint32_t blocks = 0;
   int rc = persistentGrid(s, kernel, blocks);
   if (rc) return rc;
@@ -414,7 +419,7 @@ int planLaunch(ptx_scene* s, K kernel, const FrameConstants& fc, bool wide, uint
   const size_t deepEntries = bound > ldsStack ? bound - ldsStack : 0u;  // entries beyond the kernel's LDS part
   plan.blocks = blocks;
   plan.wide = wide;
-  plan.ovfBytes = ((deepEntries ? deepEntries : 1u) + kParkSlots) * (size_t)raysPerLane * blocks * kBlockThreads * sizeof(uint32_t);
+  plan.ovfBytes = ((deepEntries ? deepEntries : 1u) + parkSlots) * (size_t)raysPerLane * blocks * kBlockThreads * sizeof(uint32_t);
   return PTX_OK;
 }
 
@@ -494,6 +499,22 @@ bool useWide(const ptx_scene* s) {
   return s->wideStackBound != 0u && !(env && env[0] == '0');
 }
 
+// PTX_QUEUE=1 in the environment sends the radiance path through queueKernel (queue_kernel.hpp).
+bool useQueue() {  // read at every launch: tests switch between the two kernels inside one process
+  const char* env = getenv("PTX_QUEUE");
+  return env && env[0] == '1';
+}
+uint32_t queueChainsPerLane() {  // chains in flight per lane of the grid (PTX_QUEUE_CHAINS, default 3)
+  const char* env = getenv("PTX_QUEUE_CHAINS");
+  const int v = env ? atoi(env) : 3;
+  return (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
+}
+uint32_t queueShards() {  // independent queue pairs (PTX_QUEUE_SHARDS, default 4)
+  const char* env = getenv("PTX_QUEUE_SHARDS");
+  const int v = env ? atoi(env) : 4;
+  return (uint32_t)(v < 1 ? 1 : (v > (int)kQMaxShards ? (int)kQMaxShards : v));
+}
+
 int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool resolve, hipStream_t stream, bool stats,
                    ScratchOwner owner = ScratchOwner::handle) {
   const bool wide = useWide(s);
@@ -517,6 +538,53 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
     }
     return (int)PTX_OK;
   };
+  // The queue kernel (queue_kernel.hpp): chains in memory, extend / shade roles around two ray queues.
+  auto goQueue = [&](auto kernel) {
+    LaunchPlan plan;
+    Scratch scr;
+    int rc = planLaunch(s, kernel, fc, true, kQStack, 1u, plan, kQParkSlots);
+    if (rc) return rc;
+    plan.planeBytes = direct ? 0u : (size_t)fc.subStreams * nPixels * sizeof(float4);
+    if ((rc = handleScratch(s, plan, scr))) return rc;
+    const uint32_t threads = plan.blocks * kBlockThreads;
+    const uint32_t work = nPixels * fc.subStreams;
+    QueueLayout q{};
+    q.chainsPerLane = std::min(queueChainsPerLane(), (work + threads - 1u) / threads);
+    const uint64_t chains = (uint64_t)q.chainsPerLane * threads;
+    if (chains >= (1ull << 24)) return fail(PTX_ELIMIT, "queue kernel: more than 2^24 chains in flight");
+    q.shards = queueShards();
+    while ((1ull << q.ringLog2) < chains) q.ringLog2++;
+    const uint64_t ringWord = (uint64_t)q.shards << q.ringLog2 << 4;  // bytes of one word array over all shards
+    uint64_t cur = (queueCtlBytes(q.shards) + 255u) & ~255ull;
+    uint32_t* ringOffsets[6] = {&q.ray0, &q.ray1, &q.shade0, &q.shade1, &q.shade2, &q.shade3};
+    for (uint32_t* o : ringOffsets) { *o = (uint32_t)cur; cur += ringWord; }
+    const uint64_t zeroBytes = cur;  // control words and rings: a tag is never 0
+    uint32_t* chainOffsets[3] = {&q.p0, &q.p1, &q.p2};
+    for (uint32_t* o : chainOffsets) { *o = (uint32_t)cur; cur += chains * 16u; }
+    if (cur >= (1ull << 32) - 4096u) return fail(PTX_ELIMIT, "queue kernel: scratch exceeds the 4 GiB a buffer descriptor addresses (fewer shards or chains)");
+    if (s->queueBytes < cur) {
+      if (s->dQueue) HIP_TRY(hipFree(s->dQueue));
+      s->dQueue = nullptr;
+      s->queueBytes = 0;
+      HIP_TRY(hipMalloc((void**)&s->dQueue, cur));
+      s->queueBytes = cur;
+    }
+    q.base = s->dQueue;
+    q.totalBytes = (uint32_t)cur;
+    HIP_TRY(hipMemsetAsync(s->dQueue, 0, zeroBytes, stream));
+    HIP_TRY(hipEventRecord(s->evStart, stream));
+    kernel<<<dim3(plan.blocks), dim3(kBlockThreads), 0, stream>>>(s->dev, fc, q, direct ? (void*)dOut : (void*)scr.planes, s->dStats, scr.overflow);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->evStop, stream));
+    s->lastStream = stream;
+    s->timed = true;
+    s->queueLaunched = true;
+    if (!direct) {
+      combineKernel<<<dim3((nPixels + 255u) / 256u), dim3(256), 0, stream>>>(scr.planes, fc.subStreams, nPixels, dOut, resolve);
+      HIP_TRY(hipGetLastError());
+    }
+    return (int)PTX_OK;
+  };
 #ifdef PTX_EXPERIMENT_PHASES
   // experimental builds: the phase kernel (radiance_kernel.hpp) unless PTX_RAD_LEGACY=1
   static const char* legacy = getenv("PTX_RAD_LEGACY");
@@ -526,13 +594,31 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
   static const char* exchange = getenv("PTX_EXCHANGE");  // experimental builds: the block-exchange kernel (exchange_kernel.hpp)
   if (wide && exchange && exchange[0] == '1') return stats ? go(exchangeKernel<true>, kXStack) : go(exchangeKernel<false>, kXStack);
 #endif
+  s->queueLaunched = false;
+  if (wide && owner == ScratchOwner::handle && useQueue()) return stats ? goQueue(queueKernel<true>) : goQueue(queueKernel<false>);
   if (wide) return stats ? go(pathKernel<kModeRadiance, true, true>, kLdsStack) : go(pathKernel<kModeRadiance, false, true>, kLdsStack);
   return stats ? go(pathKernel<kModeRadiance, true, false>, kLdsStack) : go(pathKernel<kModeRadiance, false, false>, kLdsStack);
+}
+
+// After a queueKernel launch has finished: its error word (a bounded spin ran out: queue_kernel.hpp).
+int queueVerdict(ptx_scene* s) {
+  if (!s->queueLaunched) return PTX_OK;
+  uint32_t ctl[4] = {};
+  HIP_TRY(hipMemcpy(ctl, s->dQueue, sizeof(ctl), hipMemcpyDeviceToHost));
+  s->queueLaunched = false;
+  if (ctl[kCtlError] != 0u) {
+    char buf[200];
+    snprintf(buf, sizeof(buf), "queue kernel gave up (code %u: 1 ray entry never arrived, 2 shade entry never arrived, 3 no progress for 5 s); %u items pulled, %u finished",
+             ctl[kCtlError], ctl[kCtlWork], ctl[kCtlDone]);
+    return fail(PTX_EHIP, buf);
+  }
+  return PTX_OK;
 }
 
 int kernelSeconds(ptx_scene* s, double* out) {
   if (!s->timed) return fail(PTX_EINVAL, "no launch has been made through this handle");
   HIP_TRY(hipEventSynchronize(s->evStop));
+  if (int rc = queueVerdict(s)) return rc;
   float ms = 0.0f;
   HIP_TRY(hipEventElapsedTime(&ms, s->evStart, s->evStop));
   *out = (double)ms * 1e-3;
@@ -808,6 +894,7 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
 #ifdef PTX_EXPERIMENT_PHASES
   if (!rc) rc = persistentGrid(s, radianceKernel<false>, blocks);
 #endif
+  if (!rc) rc = persistentGrid(s, queueKernel<false>, blocks);
   if (!rc) rc = persistentGrid(s, pathKernel<kModeRadiance, false, true>, blocks);
   if (!rc) rc = persistentGrid(s, pathKernel<kModeRadiance, false, false>, blocks);
   if (rc) {
@@ -1019,6 +1106,7 @@ void ptx_destroy(ptx_scene* s) {
   if (s->dOverflow) (void)hipFree(s->dOverflow);
   if (s->dRows) (void)hipFree(s->dRows);
   if (s->dPlanes) (void)hipFree(s->dPlanes);
+  if (s->dQueue) (void)hipFree(s->dQueue);
   if (s->dGather) (void)hipFree(s->dGather);
   if (s->ownStream) (void)hipStreamDestroy(s->ownStream);
   if (s->evPart) (void)hipEventDestroy(s->evPart);
@@ -1095,6 +1183,7 @@ int ptx_render(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, float
   if ((rc = ensureOut(s, bytes))) return rc;
   if ((rc = launchRadiance(s, fc, (float*)s->outBuf, true, nullptr, false))) return rc;
   HIP_TRY(hipMemcpy(out, s->outBuf, bytes, hipMemcpyDeviceToHost));
+  if ((rc = queueVerdict(s))) return rc;
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     stats->upload_s = s->uploadSeconds;
@@ -1161,6 +1250,7 @@ int ptx_render_bgr8(ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, 
   quantiseKernel<<<dim3((n + 255u) / 256u), dim3(256)>>>((const float*)s->outBuf, prm->width, n, rowBytes, s->dRows);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, s->dRows, bytes, hipMemcpyDeviceToHost));
+  if ((rc = queueVerdict(s))) return rc;
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     stats->upload_s = s->uploadSeconds;
@@ -1253,6 +1343,10 @@ int ptx_render_multi(ptx_scene* const* scenes, uint32_t count, const ptx_camera*
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, root->outBuf, nPixels * 3u * sizeof(float), hipMemcpyDeviceToHost, root->ownStream));
   HIP_TRY(hipStreamSynchronize(root->ownStream));
+  for (uint32_t i = 0; i < count; i++) {
+    HIP_TRY(hipSetDevice(scenes[i]->device));
+    if ((rc = queueVerdict(scenes[i]))) return rc;
+  }
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     stats->upload_s = root->uploadSeconds;

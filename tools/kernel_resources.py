@@ -39,6 +39,9 @@ def kernels(text):
         if m:
             name = "pathKernel<%s, %s, %s>" % ("radiance" if m.group(1) == "1" else "counts",
                                                "stats" if m.group(2) == "1" else "plain", "wide" if m.group(3) == "1" else "binary")
+        m = re.match(r"_ZN3ptx11queueKernelILb(\d)E", name)
+        if m:
+            name = "queueKernel<%s>" % ("stats" if m.group(1) == "1" else "plain")
         f["waves_per_simd"] = min(8, 512 // max(f["vgpr_count"], 1) if f["vgpr_count"] > 64 else 8)
         res[name] = f
     return res
@@ -62,7 +65,7 @@ if __name__ == "__main__":
     extra = [a for a in args if a != "--regions"] + (["-DPTX_ISA_MARKERS"] if regions else [])
     text = compile_to_asm(extra)
     for name, f in kernels(text).items():
-        if "pathKernel" in name:
+        if "pathKernel" in name or "queueKernel" in name:
             print(json.dumps({"kernel": name, **f}))
     if regions:
         for region, line in scratch_by_region(text):
