@@ -31,7 +31,8 @@
 // pathKernel, so the image is bit-identical to it for equal seeds and streams.
 #pragma once
 
-#include "kernels.hpp"
+#include "../path-tracer_amd/csrc/kernels.hpp"
+#include "../path-tracer_amd/csrc/pool_kernel.hpp"  // laneRank, fbits, bitsf
 
 namespace ptx {
 
@@ -87,12 +88,17 @@ __device__ __forceinline__ void queueStore(__amdgpu_buffer_rsrc_t rsrc, uint32_t
   __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)off, 0, 16);
 }
 
-__device__ __forceinline__ uint32_t laneRank(unsigned long long mask) {  // set bits of `mask` below this lane
-  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint32_t fbits(float f) { return __float_as_uint(f); }
-__device__ __forceinline__ float bitsf(uint32_t u) { return __uint_as_float(u); }
+
+// Profiling builds (-DPTX_QUEUE_DEBUG): per-wave event counts, added to 16 words behind the control words when a wave leaves
+// (read with ptx_debug_queue_counters): 0 services, 1 pop claims tried, 2 pop claims lost, 3 rays taken, 4 batch claims tried,
+// 5 batch claims lost, 6 batches, 7 lanes in batches, 8 re-reads of ray entries, 9 re-reads of shade entries, 10 idle rounds,
+// 11 loop iterations, 12 starved services, 13 rays delivered
+#ifdef PTX_QUEUE_DEBUG
+#define PTX_QDBG(k, n) do { dbg[k] += (n); } while (0)
+#else
+#define PTX_QDBG(k, n) do {} while (0)
+#endif
 
 template <bool STATS>
 __global__ void __launch_bounds__(kBlockThreads, PTX_QUEUE_MIN_WAVES) queueKernel(DeviceScene sc, FrameConstants fcArg, QueueLayout qArg,
@@ -129,8 +135,12 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_QUEUE_MIN_WAVES) queueKerne
   unsigned long long idleSince = 0ull;
   uint32_t idleMark = 0u;
   bool leave = false;
+#ifdef PTX_QUEUE_DEBUG
+  uint32_t dbg[16] = {};
+#endif
 
   for (;;) {
+    PTX_QDBG(11, 1u);
     const bool fin = ref == kRefDone, vacant = ref == kRefIdle;
     const unsigned long long finMask = __ballot(fin), vacantMask = __ballot(vacant);
     const uint32_t nFin = (uint32_t)__popcll(finMask), nVacant = (uint32_t)__popcll(vacantMask);
@@ -148,6 +158,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_QUEUE_MIN_WAVES) queueKerne
       const uint32_t nPixels = fc.width * fc.height;
       const uint32_t totalWork = nPixels * fc.subStreams;
       const bool births = birthsDone < q.chainsPerLane;
+      PTX_QDBG(0, 1u);
 
       // ---- the counters: one round trip for the delivery's reservation and a look at the queues, one more for the claims ----
       const unsigned long long wantMask = finMask | vacantMask;
@@ -184,6 +195,15 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_QUEUE_MIN_WAVES) queueKerne
         nShade = uniform(nShade);
         shadeBase = uniform(shadeBase);
         if (nPop == 0xFFFFFFFFu) break;
+#ifdef PTX_QUEUE_DEBUG
+        {
+          const uint32_t triedPop = uniform(lane == 0u && !births && (int32_t)(rt - rh) > 0 && nWant ? 1u : 0u);
+          const uint32_t triedShade = uniform(lane == 0u && !births && ((int32_t)(st - sh) >= 64 || ((int32_t)(rt - rh) < (int32_t)nWant && (int32_t)(st - sh) > 0)) ? 1u : 0u);
+          PTX_QDBG(1, triedPop); PTX_QDBG(2, triedPop && !nPop ? 1u : 0u);
+          PTX_QDBG(4, triedShade); PTX_QDBG(5, triedShade && !nShade ? 1u : 0u);
+          PTX_QDBG(3, nPop); PTX_QDBG(13, nFin);
+        }
+#endif
       }
 
       // ---- (A) deliver the finished rays: one shadeQ entry each ----
@@ -213,6 +233,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_QUEUE_MIN_WAVES) queueKerne
           w1 = PTX_QLOAD(rs, q.ray1 + off);
           const bool ok = !take || (w0.w == tag && (w1.w >> 24) == tag8);
           if (__all(ok)) break;
+          PTX_QDBG(8, 1u);
           if (spins > kQSpinLimit) {
             if (lane == 0u) __hip_atomic_store(ctl + kCtlError, 1u, PTX_RLX_AGENT);
             leave = true;
@@ -245,6 +266,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_QUEUE_MIN_WAVES) queueKerne
       }
       const bool starved = !births && nPop < nWant;
       if (starved) {
+        PTX_QDBG(12, 1u);
         cooldown = PTX_QUEUE_COOLDOWN;
         popShard++;  // look into another shard next time
       }
@@ -264,6 +286,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_QUEUE_MIN_WAVES) queueKerne
         }
 
         const bool valid = births || lane < nShade;
+        PTX_QDBG(6, 1u); PTX_QDBG(7, births ? 64u : nShade);
         bool birth = births;
         vec3 ro(0.0f), rd(0.0f, 0.0f, -1.0f);
         Hit h;
@@ -281,6 +304,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_QUEUE_MIN_WAVES) queueKerne
             w3 = PTX_QLOAD(rs, q.shade3 + off);
             const bool ok = !valid || (w0.w == tag && w1.w == tag && w2.w == tag && w3.w == tag);
             if (__all(ok)) break;
+            PTX_QDBG(9, 1u);
             if (spins > kQSpinLimit) {
               if (lane == 0u) __hip_atomic_store(ctl + kCtlError, 2u, PTX_RLX_AGENT);
               leave = true;
@@ -418,6 +442,7 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_QUEUE_MIN_WAVES) queueKerne
       } else if (!leave && nFin + nVacant == 64u && nPop == 0u) {
         // ---- (D) nothing to trace, nothing to shade: finished, or wait for the others ----
         uint32_t doneItems = 0u, err = 0u, progress = 0u;
+        PTX_QDBG(10, 1u);
         if (lane == 0u) {
           doneItems = __hip_atomic_load(ctl + kCtlDone, PTX_RLX_AGENT);
           err = __hip_atomic_load(ctl + kCtlError, PTX_RLX_AGENT);
@@ -538,6 +563,12 @@ __global__ void __launch_bounds__(kBlockThreads, PTX_QUEUE_MIN_WAVES) queueKerne
     }
   }
 
+#ifdef PTX_QUEUE_DEBUG
+  if (lane == 0u) {
+    const QueueLayout q = loadKernelArgument<QueueLayout>((uint32_t)offsetof(QueueKernelArgs, q));
+    for (int k = 0; k < 16; k++) atomicAdd((uint32_t*)q.base + queueCtlBytes(q.shards) / 4u + k, dbg[k]);
+  }
+#endif
   if (STATS) {
     atomicAdd(&stats->rays, (unsigned long long)nRays);
     atomicAdd(&stats->nodeSteps, (unsigned long long)nNodeSteps);

@@ -133,6 +133,8 @@ struct FrameConstants {
   uint32_t widthMul, widthShift;  // n / width for n < 2^24: umulhi(n << 8, widthMul) >> widthShift
   uint32_t bandMul, bandShift;    // the same for n / (8 * width)
   double invPixels;               // 1.0 / (width * height)
+  uint32_t scatterMul;            // poolKernel: item w renders pixel slot (w * scatterMul) mod pixels (0: slot w); see makeFrame
+  uint32_t padTail;
 };
 
 struct DeviceStats {  // accumulated with atomics by the instrumented kernel variants

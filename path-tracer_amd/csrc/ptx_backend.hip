@@ -22,7 +22,10 @@
 #ifdef PTX_EXPERIMENT_EXCHANGE  // DESIGN.md section 3, "block exchange": measured slower, kept for A/B builds only
 #include "exchange_kernel.hpp"
 #endif
-#include "queue_kernel.hpp"
+#include "pool_kernel.hpp"
+#ifdef PTX_EXPERIMENT_QUEUES  // global shared ray queues: measured 6-50x slower (profiles/r03/global_queues.txt), A/B builds only
+#include "../../experiments/queue_kernel.hpp"
+#endif
 #include "tight_bounds.hpp"
 #include "wide_bvh.hpp"
 
@@ -347,6 +350,21 @@ int makeFrame(const ptx_scene* s, const ptx_camera* cam, const ptx_params* prm, 
     fc.bandShift = sh;
     fc.bandMul = (uint32_t)((((uint64_t)1 << (24 + sh)) + band - 1u) / band);
   }
+  {
+    // Long work items (16 samples or more of one RNG stream: the reference's seeding) are handed to the pool kernel's waves
+    // scattered over the image, item w -> pixel slot (w * a) mod pixels with a coprime to the pixel count and near
+    // pixels / golden ratio, so that every wave holds expensive and cheap pixels (pool_kernel.hpp); short items keep the
+    // 8x8 blocks of adjacent pixels.  PTX_SCATTER=0 / 1 overrides (A/B measurements).
+    const char* env = getenv("PTX_SCATTER");
+    const bool scatter = env ? env[0] == '1' : fc.sppBase >= 16u;
+    if (scatter && !heatmap) {
+      const uint64_t n = (uint64_t)prm->width * prm->height;
+      uint64_t a = (uint64_t)((double)n * 0.6180339887498949);
+      auto gcd = [](uint64_t x, uint64_t y) { while (y) { const uint64_t t = x % y; x = y; y = t; } return x; };
+      while (a > 1 && gcd(a, n) != 1) a--;
+      fc.scatterMul = (uint32_t)(a > 1 ? a : 0);
+    }
+  }
   fc.seedBase = 1023u;
   // stream id of this call's k-th stream = part_index * sub_streams + k with the REQUESTED sub_streams: a part whose
   // share of the samples is smaller than that runs fewer streams, and its ids must not slide into its neighbour's
@@ -426,6 +444,7 @@ int planLaunch(ptx_scene* s, K kernel, const FrameConstants& fc, bool wide, uint
 template <typename K>
 int launchPath(ptx_scene* s, K kernel, const FrameConstants& fc, const LaunchPlan& plan, const Scratch& scr, void* dOut,
                hipStream_t stream) {
+  if (getenv("PTX_DEBUG_LAUNCH")) fprintf(stderr, "[ptx] pathKernel: %u blocks (%d CUs), %u streams\n", plan.blocks, s->numCus, fc.subStreams);
   HIP_TRY(hipMemsetAsync(scr.workCounter, 0, sizeof(uint32_t), stream));
   HIP_TRY(hipEventRecord(s->evStart, stream));
   kernel<<<dim3(plan.blocks), dim3(kBlockThreads), 0, stream>>>(s->dev, fc, scr.workCounter, dOut, s->dStats, scr.overflow);
@@ -499,21 +518,31 @@ bool useWide(const ptx_scene* s) {
   return s->wideStackBound != 0u && !(env && env[0] == '0');
 }
 
-// PTX_QUEUE=1 in the environment sends the radiance path through queueKernel (queue_kernel.hpp).
-bool useQueue() {  // read at every launch: tests switch between the two kernels inside one process
+// Which kernel traces radiance on the wide layout: poolKernel (pool_kernel.hpp) unless PTX_QUEUE=0 (pathKernel: A/B, tests);
+// PTX_QUEUE=2 the global-queue experiment where it is compiled in.  Read at every launch: tests switch inside one process.
+int radianceKernelChoice() {
   const char* env = getenv("PTX_QUEUE");
-  return env && env[0] == '1';
+  return env ? atoi(env) : 1;
 }
-uint32_t queueChainsPerLane() {  // chains in flight per lane of the grid (PTX_QUEUE_CHAINS, default 3)
+// Chains per lane of the grid: 2 for short work items (sub-streams), 3 for long ones, where all of the frame's chains should
+// be under way from the start (profiles/r03/pool_chains_ab.txt); PTX_POOL_CHAINS overrides.
+uint32_t poolChainsPerLane(const FrameConstants& fc) {
+  const char* env = getenv("PTX_POOL_CHAINS");
+  const int v = env ? atoi(env) : (fc.sppBase >= 16u ? 3 : 2);
+  return (uint32_t)(v < 1 ? 1 : (v > (int)kPMaxChainsPerLane ? (int)kPMaxChainsPerLane : v));
+}
+#ifdef PTX_EXPERIMENT_QUEUES
+uint32_t queueChainsPerLane() {
   const char* env = getenv("PTX_QUEUE_CHAINS");
   const int v = env ? atoi(env) : 3;
   return (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
 }
-uint32_t queueShards() {  // independent queue pairs (PTX_QUEUE_SHARDS, default 4)
+uint32_t queueShards() {
   const char* env = getenv("PTX_QUEUE_SHARDS");
   const int v = env ? atoi(env) : 4;
   return (uint32_t)(v < 1 ? 1 : (v > (int)kQMaxShards ? (int)kQMaxShards : v));
 }
+#endif
 
 int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool resolve, hipStream_t stream, bool stats,
                    ScratchOwner owner = ScratchOwner::handle) {
@@ -538,6 +567,45 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
     }
     return (int)PTX_OK;
   };
+  // The pool kernel (pool_kernel.hpp): a private pool of chains per wave, shading in batches of 64.
+  auto goPool = [&](auto kernel) {
+    LaunchPlan plan;
+    Scratch scr;
+    int rc = planLaunch(s, kernel, fc, true, kPStack, 1u, plan, kPParkSlots);
+    if (rc) return rc;
+    plan.planeBytes = direct ? 0u : (size_t)fc.subStreams * nPixels * sizeof(float4);
+    if ((rc = handleScratch(s, plan, scr))) return rc;
+    const uint32_t threads = plan.blocks * kBlockThreads;
+    const uint32_t work = nPixels * fc.subStreams;
+    PoolLayout q{};
+    q.chainsPerLane = std::min(poolChainsPerLane(fc), (work + threads - 1u) / threads);
+    const size_t bytes = (size_t)(threads / 64u) * 64u * q.chainsPerLane * kPSlotBytes + 256u;
+    if (s->queueBytes < bytes) {
+      if (s->dQueue) HIP_TRY(hipFree(s->dQueue));
+      s->dQueue = nullptr;
+      s->queueBytes = 0;
+      HIP_TRY(hipMalloc((void**)&s->dQueue, bytes));
+      s->queueBytes = bytes;
+    }
+    q.base = s->dQueue;
+    if (getenv("PTX_DEBUG_LAUNCH"))
+      fprintf(stderr, "[ptx] poolKernel: %u blocks (%d CUs), %u chains per lane, scatter %u, %u streams, %zu bytes of chain records\n", plan.blocks,
+              s->numCus, q.chainsPerLane, fc.scatterMul, fc.subStreams, bytes);
+    HIP_TRY(hipMemsetAsync(scr.workCounter, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipEventRecord(s->evStart, stream));
+    kernel<<<dim3(plan.blocks), dim3(kBlockThreads), 0, stream>>>(s->dev, fc, q, scr.workCounter, direct ? (void*)dOut : (void*)scr.planes, s->dStats,
+                                                                   scr.overflow);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->evStop, stream));
+    s->lastStream = stream;
+    s->timed = true;
+    if (!direct) {
+      combineKernel<<<dim3((nPixels + 255u) / 256u), dim3(256), 0, stream>>>(scr.planes, fc.subStreams, nPixels, dOut, resolve);
+      HIP_TRY(hipGetLastError());
+    }
+    return (int)PTX_OK;
+  };
+#ifdef PTX_EXPERIMENT_QUEUES
   // The queue kernel (queue_kernel.hpp): chains in memory, extend / shade roles around two ray queues.
   auto goQueue = [&](auto kernel) {
     LaunchPlan plan;
@@ -555,7 +623,7 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
     q.shards = queueShards();
     while ((1ull << q.ringLog2) < chains) q.ringLog2++;
     const uint64_t ringWord = (uint64_t)q.shards << q.ringLog2 << 4;  // bytes of one word array over all shards
-    uint64_t cur = (queueCtlBytes(q.shards) + 255u) & ~255ull;
+    uint64_t cur = (queueCtlBytes(q.shards) + 64u /* debug counters of profiling builds */ + 255u) & ~255ull;
     uint32_t* ringOffsets[6] = {&q.ray0, &q.ray1, &q.shade0, &q.shade1, &q.shade2, &q.shade3};
     for (uint32_t* o : ringOffsets) { *o = (uint32_t)cur; cur += ringWord; }
     const uint64_t zeroBytes = cur;  // control words and rings: a tag is never 0
@@ -585,6 +653,7 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
     }
     return (int)PTX_OK;
   };
+#endif
 #ifdef PTX_EXPERIMENT_PHASES
   // experimental builds: the phase kernel (radiance_kernel.hpp) unless PTX_RAD_LEGACY=1
   static const char* legacy = getenv("PTX_RAD_LEGACY");
@@ -595,7 +664,10 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
   if (wide && exchange && exchange[0] == '1') return stats ? go(exchangeKernel<true>, kXStack) : go(exchangeKernel<false>, kXStack);
 #endif
   s->queueLaunched = false;
-  if (wide && owner == ScratchOwner::handle && useQueue()) return stats ? goQueue(queueKernel<true>) : goQueue(queueKernel<false>);
+#ifdef PTX_EXPERIMENT_QUEUES
+  if (wide && owner == ScratchOwner::handle && radianceKernelChoice() == 2) return stats ? goQueue(queueKernel<true>) : goQueue(queueKernel<false>);
+#endif
+  if (wide && owner == ScratchOwner::handle && radianceKernelChoice() == 1) return stats ? goPool(poolKernel<true>) : goPool(poolKernel<false>);
   if (wide) return stats ? go(pathKernel<kModeRadiance, true, true>, kLdsStack) : go(pathKernel<kModeRadiance, false, true>, kLdsStack);
   return stats ? go(pathKernel<kModeRadiance, true, false>, kLdsStack) : go(pathKernel<kModeRadiance, false, false>, kLdsStack);
 }
@@ -603,6 +675,7 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
 // After a queueKernel launch has finished: its error word (a bounded spin ran out: queue_kernel.hpp).
 int queueVerdict(ptx_scene* s) {
   if (!s->queueLaunched) return PTX_OK;
+#ifdef PTX_EXPERIMENT_QUEUES
   uint32_t ctl[4] = {};
   HIP_TRY(hipMemcpy(ctl, s->dQueue, sizeof(ctl), hipMemcpyDeviceToHost));
   s->queueLaunched = false;
@@ -612,6 +685,7 @@ int queueVerdict(ptx_scene* s) {
              ctl[kCtlError], ctl[kCtlWork], ctl[kCtlDone]);
     return fail(PTX_EHIP, buf);
   }
+#endif
   return PTX_OK;
 }
 
@@ -894,7 +968,7 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
 #ifdef PTX_EXPERIMENT_PHASES
   if (!rc) rc = persistentGrid(s, radianceKernel<false>, blocks);
 #endif
-  if (!rc) rc = persistentGrid(s, queueKernel<false>, blocks);
+  if (!rc) rc = persistentGrid(s, poolKernel<false>, blocks);
   if (!rc) rc = persistentGrid(s, pathKernel<kModeRadiance, false, true>, blocks);
   if (!rc) rc = persistentGrid(s, pathKernel<kModeRadiance, false, false>, blocks);
   if (rc) {
@@ -1421,6 +1495,27 @@ int ptx_last_kernel_seconds(ptx_scene* s, double* seconds) {
 }
 
 }  // extern "C"
+
+#if defined(PTX_QUEUE_DEBUG) && defined(PTX_EXPERIMENT_QUEUES)
+// Profiling builds only: the event counters of the last queueKernel launch through this handle (queue_kernel.hpp).
+extern "C" int ptx_debug_queue_counters(ptx_scene* s, unsigned int* out16) {
+  if (!s || !s->dQueue) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpy(out16, s->dQueue + queueCtlBytes(queueShards()), 64, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  return 0;
+}
+#endif
+
+#ifdef PTX_POOL_PROFILE
+// Profiling builds only: reads and clears the pool kernel's region profile (pool_kernel.hpp).
+extern "C" int ptx_debug_pool_profile(unsigned long long* out16) {
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ptx::gPoolProfile), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
+  unsigned long long zero[32] = {};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(ptx::gPoolProfile), zero, sizeof(zero)) != hipSuccess) return -2;
+  return 0;
+}
+#endif
 
 #ifdef PTX_WAVE_PROFILE
 // Profiling builds only (not declared in include/ptx_backend.h): reads and clears the wave profile.

@@ -39,9 +39,9 @@ def kernels(text):
         if m:
             name = "pathKernel<%s, %s, %s>" % ("radiance" if m.group(1) == "1" else "counts",
                                                "stats" if m.group(2) == "1" else "plain", "wide" if m.group(3) == "1" else "binary")
-        m = re.match(r"_ZN3ptx11queueKernelILb(\d)E", name)
+        m = re.match(r"_ZN3ptx(\d+)(queueKernel|poolKernel)ILb(\d)E", name)
         if m:
-            name = "queueKernel<%s>" % ("stats" if m.group(1) == "1" else "plain")
+            name = "%s<%s>" % (m.group(2), "stats" if m.group(3) == "1" else "plain")
         f["waves_per_simd"] = min(8, 512 // max(f["vgpr_count"], 1) if f["vgpr_count"] > 64 else 8)
         res[name] = f
     return res
@@ -59,14 +59,29 @@ def scratch_by_region(text, mangled="_ZN3ptx10pathKernelILi1ELb0ELb1E"):
     return out
 
 
+def pool_spill_ops_by_region(text, mangled="_ZN3ptx10poolKernelILb0E"):
+    """{region: count} of spill traffic (scratch_*, v_readlane / v_writelane) in poolKernel, regions by its PTXMARKs
+    (compile with -DPTX_ISA_MARKERS): PRE, SERVICE, TRAV_BEGIN (the traversal step), TRAV_END."""
+    m = re.search(r"^" + mangled + r".*?:\n(.*?)s_endpgm", text, re.S | re.M)
+    region, out = "PRE", {}
+    for line in m.group(1).splitlines():
+        mm = re.search(r"PTXMARK (\w+)", line)
+        if mm:
+            region = mm.group(1)
+        elif "scratch_" in line or "v_readlane_b32" in line or "v_writelane_b32" in line:
+            out[region] = out.get(region, 0) + 1
+    return out
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
     regions = "--regions" in args
     extra = [a for a in args if a != "--regions"] + (["-DPTX_ISA_MARKERS"] if regions else [])
     text = compile_to_asm(extra)
     for name, f in kernels(text).items():
-        if "pathKernel" in name or "queueKernel" in name:
+        if "Kernel<" in name:
             print(json.dumps({"kernel": name, **f}))
     if regions:
         for region, line in scratch_by_region(text):
             print(f"  {region:12s} {line}")
+        print("poolKernel spill traffic by region:", pool_spill_ops_by_region(text))

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Where a wave of poolKernel spends its time (a -DPTX_POOL_PROFILE build: PTX_BACKEND_LIB=.../libptx_backend_pprof.so).
+usage: tools/pool_profile.py [spp] [streams] [scene]"""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "path-tracer_amd", "py"))
+import ptamd
+
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+streams = int(sys.argv[2]) if len(sys.argv) > 2 else 34
+scene = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+os.environ["PTX_QUEUE"] = "1"
+s = ptamd.HostScene(scene, cache_dir="/tmp/pt_scene_cache")
+d = ptamd.DeviceScene(s.desc_ptr)
+p = ptamd.make_params(1500, 800, spp=spp, max_bounces=6, seed_mode=1 if streams > 1 else 0, sub_streams=streams)
+lib = ptamd.backend_lib()
+out = (C.c_ulonglong * 16)()
+img, st = d.render(s.camera, p)
+lib.ptx_debug_pool_profile(out)  # clear what the warm-up left
+img, st = d.render(s.camera, p)
+lib.ptx_debug_pool_profile(out)
+v = list(out)
+ticks = sum(v[:5])
+names = ["loop top", "delivery", "shading batch", "refill", "traversal step"]
+print(f"poolKernel, scene {scene}, 1500x800, {spp} spp, {streams} streams, chains/lane {os.environ.get('PTX_POOL_CHAINS', '3')}: {st.render_s * 1e3:.1f} ms")
+for n, t in zip(names, v[:5]):
+    print(f"  {n:16s} {100.0 * t / ticks:5.1f} % of wave time")
+it, sv, ba, sh, dl, tk, ls, vac = v[8:16]
+print(f"  iterations {it}, services {sv} (one per {it / max(sv, 1):.1f} iterations), batches {ba} with {sh / max(ba, 1):.1f} chains, "
+      f"rays delivered {dl} ({dl / max(sv, 1):.1f} per service), taken {tk}")
+print(f"  lanes stepping per iteration {ls / max(it, 1):.1f}, lanes without a ray per iteration {vac / max(it, 1):.1f}")
+print(f"  ticks per iteration: traversal {v[4] / max(it, 1):.0f}; per service: delivery {v[1] / max(sv, 1):.0f}, refill {v[3] / max(sv, 1):.0f}; per batch: {v[2] / max(ba, 1):.0f}")

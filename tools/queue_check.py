@@ -13,7 +13,7 @@ import sys, os, json, time, zlib
 sys.path.insert(0, os.path.join(%(repo)r, "path-tracer_amd", "py"))
 import numpy as np, ptamd
 scene, w, h, spp, bounces, streams, iters = %(scene)d, %(w)d, %(h)d, %(spp)d, %(bounces)d, %(streams)d, %(iters)d
-s = ptamd.HostScene(scene, cache_dir=os.path.join(%(repo)r, "gpurun_out", "scene_cache")); d = ptamd.DeviceScene(s.desc_ptr)
+s = ptamd.HostScene(scene, cache_dir="/tmp/pt_scene_cache"); d = ptamd.DeviceScene(s.desc_ptr)
 p = ptamd.make_params(w, h, spp=spp, max_bounces=bounces, seed_mode=1 if streams > 1 else 0, sub_streams=streams)
 out = {}
 imgs = {}
