@@ -31,7 +31,7 @@
 // pathKernel pays in idle lanes is less than what the exchange pays in waiting waves.
 #pragma once
 
-#include "kernels.hpp"
+#include "../path-tracer_amd/csrc/kernels.hpp"
 
 namespace ptx {
 

@@ -33,7 +33,7 @@
 // per-lane branch.
 #pragma once
 
-#include "kernels.hpp"
+#include "../path-tracer_amd/csrc/kernels.hpp"
 
 namespace ptx {
 

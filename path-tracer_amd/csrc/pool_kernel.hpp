@@ -42,7 +42,7 @@ namespace ptx {
 #define PTX_POOL_SERVE_LANES 12    // finished lanes that make a wave deliver and refill
 #endif
 constexpr uint32_t kPStack = PTX_POOL_LDS_STACK;
-constexpr uint32_t kPParkSlots = 20u;        // dwords of traversal state parked around a shading batch
+constexpr uint32_t kPParkSlots = 14u;        // dwords of traversal state parked around a shading batch
 constexpr uint32_t kPMaxChainsPerLane = 3u;  // slot ids are bytes; three lists of 192 bytes per wave fit beside the stack
 constexpr uint32_t kPMaxSlots = 64u * kPMaxChainsPerLane;
 constexpr uint32_t kPWordArrays = 6u;        // R0 R1 H0 P0 P1 P2 (16 bytes per slot each), then H1 (4 bytes per slot)
@@ -269,10 +269,9 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
       if (nShade) {
         {
           // the wave's own rays wait in memory meanwhile (pathKernel: PTX_PARK; unconditional, or the compiler keeps the
-          // registers); wo / wd are in the chain's slot already
-          const uint32_t pv[kPParkSlots] = {fbits(o.x),   fbits(o.y),   fbits(o.z),   fbits(d.x),   fbits(d.y),  fbits(d.z),  fbits(inv.x),
-                                            fbits(inv.y), fbits(inv.z), fbits(hit.t), fbits(hit.u), fbits(hit.v), hit.tri,    hit.inst,
-                                            tlasLeaf,     curInst,      fbits(winv.x), fbits(winv.y), fbits(winv.z), chain};
+          // registers); wo / wd are in the chain's slot already, the two reciprocal directions are computed again afterwards
+          const uint32_t pv[kPParkSlots] = {fbits(o.x),   fbits(o.y),   fbits(o.z),   fbits(d.x), fbits(d.y), fbits(d.z), fbits(hit.t),
+                                            fbits(hit.u), fbits(hit.v), hit.tri,      hit.inst,   tlasLeaf,   curInst,    chain};
           uint32_t off = stk.laneBytes;
           asm volatile("" : "+v"(off));  // the addresses are computed here, one after the other, not held across the loop
 #pragma unroll
@@ -415,15 +414,18 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
           for (uint32_t i = 0; i < kPParkSlots; i++) { pv[i] = PTX_PLD(reinterpret_cast<uint32_t*>(stk.area + (size_t)off)); off += stk.strideBytes; }
           o = vec3(bitsf(pv[0]), bitsf(pv[1]), bitsf(pv[2]));
           d = vec3(bitsf(pv[3]), bitsf(pv[4]), bitsf(pv[5]));
-          inv = vec3(bitsf(pv[6]), bitsf(pv[7]), bitsf(pv[8]));
-          hit.t = bitsf(pv[9]); hit.u = bitsf(pv[10]); hit.v = bitsf(pv[11]);
-          hit.tri = pv[12]; hit.inst = pv[13];
-          tlasLeaf = pv[14]; curInst = pv[15];
-          winv = vec3(bitsf(pv[16]), bitsf(pv[17]), bitsf(pv[18]));
-          chain = pv[19];
+          hit.t = bitsf(pv[6]); hit.u = bitsf(pv[7]); hit.v = bitsf(pv[8]);
+          hit.tri = pv[9]; hit.inst = pv[10];
+          tlasLeaf = pv[11]; curInst = pv[12];
+          chain = pv[13];
           const u32x4 a0 = PTX_PLD(words + (chain)), a1 = PTX_PLD(words + (slots + chain));  // a lane without a ray reads slot `chain` of old: unused
           wo = vec3(bitsf(a0.x), bitsf(a0.y), bitsf(a0.z));
           wd = vec3(bitsf(a0.w), bitsf(a1.x), bitsf(a1.y));
+          // 1 / d as it was: the short and the long form of reciprocalDir agree bit for bit wherever the short one is used
+          bool z0, z1;
+          reciprocalDir(d, inv, z0);
+          reciprocalDir(wd, winv, z1);
+          (void)z0; (void)z1;
         }
       }
 

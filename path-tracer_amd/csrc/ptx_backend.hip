@@ -17,10 +17,10 @@
 #include "device_scene.hpp"
 #include "kernels.hpp"
 #ifdef PTX_EXPERIMENT_PHASES  // DESIGN.md section 3, "phase kernel": measured slower, kept for A/B builds only
-#include "radiance_kernel.hpp"
+#include "../../experiments/radiance_kernel.hpp"
 #endif
 #ifdef PTX_EXPERIMENT_EXCHANGE  // DESIGN.md section 3, "block exchange": measured slower, kept for A/B builds only
-#include "exchange_kernel.hpp"
+#include "../../experiments/exchange_kernel.hpp"
 #endif
 #include "pool_kernel.hpp"
 #ifdef PTX_EXPERIMENT_QUEUES  // global shared ray queues: measured 6-50x slower (profiles/r03/global_queues.txt), A/B builds only

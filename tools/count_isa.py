@@ -9,7 +9,7 @@ cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ff
        f"{REPO}/path-tracer_amd/csrc/ptx_backend.hip", "-o", f"{tmp}/k.s"] + sys.argv[1:]
 subprocess.check_call(cmd)
 text = open(f"{tmp}/k.s").read()
-# ISA_KERNEL=radiance: the phase kernel (radiance_kernel.hpp); default: pathKernel, radiance, binary (ISA_WIDE=1: wide)
+# ISA_KERNEL=radiance: the phase kernel (experiments/radiance_kernel.hpp); default: pathKernel, radiance, binary (ISA_WIDE=1: wide)
 if os.environ.get("ISA_KERNEL") == "radiance":
     pat = r"^_ZN3ptx14radianceKernelILb0EEE.*?:\n(.*?)s_endpgm"
 else:

@@ -23,7 +23,7 @@ buf = (ctypes.c_ulonglong * 32)()
 lib.ptx_debug_wave_profile(buf)  # clear
 st = d.measure(s.camera, p)
 assert lib.ptx_debug_wave_profile(buf) == 0
-# radiance_kernel.hpp (wide layout, default) / kernels.hpp pathKernel (PTX_RAD_LEGACY=1 or PTX_WIDE=0)
+# experiments/radiance_kernel.hpp (wide layout, default) / kernels.hpp pathKernel (PTX_RAD_LEGACY=1 or PTX_WIDE=0)
 legacy = os.environ.get("PTX_RAD_LEGACY") == "1" or os.environ.get("PTX_WIDE") == "0"
 names = (["loop", "shade", "step", "leaving", "enter", "tri", "node", "node-exact"] if legacy else
          ["loop", "shade", "node", "tri", "enter", "tail only", "deep stack", "exit (in tail)"])
