@@ -18,7 +18,7 @@ HOST_SRC = $(HOST)/scene.cpp $(HOST)/loaders.cpp $(HOST)/sample_scenes.cpp $(HOS
            $(HOST)/output.cpp $(HOST)/capi.cpp
 HOST_HDR = $(wildcard $(HOST)/*.hpp) include/ptx_backend.h include/pt_host.h
 HIP_SRC  = $(CSRC)/ptx_backend.hip
-HIP_HDR  = $(wildcard $(CSRC)/*.hpp) $(HOST)/ptmath.hpp $(HOST)/rng.hpp include/ptx_backend.h
+HIP_HDR  = $(wildcard $(CSRC)/*.hpp) $(HOST)/ptmath.hpp $(HOST)/rng.hpp $(HOST)/colors.hpp include/ptx_backend.h
 
 all: host backend cli oracle
 
@@ -32,9 +32,10 @@ $(LIB)/libpt_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIB)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -lz
 
-$(LIB)/libptx_backend.so: $(HIP_SRC) $(HIP_HDR)
+# the library carries the hash of its sources and flags (ptx_build_id(): tools/source_hash.py)
+$(LIB)/libptx_backend.so: $(HIP_SRC) $(HIP_HDR) tools/source_hash.py
 	@mkdir -p $(LIB)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+	$(HIPCC) $(HIPFLAGS) -DPTX_BUILD_ID=\"$(shell python3 tools/source_hash.py "$(HIPFLAGS)")\" -shared -o $@ $(HIP_SRC)
 
 $(PKG)/PathTracer: $(HOST)/main.cpp $(HOST)/gpu_render.cpp $(LIB)/libpt_host.so $(LIB)/libptx_backend.so
 	$(CXX) $(CXXFLAGS) -o $@ $(HOST)/main.cpp $(HOST)/gpu_render.cpp -L$(LIB) -lpt_host -lptx_backend \

@@ -61,6 +61,7 @@ LANE_ACCESS_PEAK_G = 256 * (64 / 45.2) * 2.4  # G lane-accesses/s for 256 CUs at
 # VALU issue: one plain wave64 instruction per 2.5 cycles and SIMD (profiles/r01/ubench_valu2.txt: 2.4-2.7 for
 # fma / mul / add / logic at 4-8 waves per SIMD; min / max / compare / select classes issue slower on their own)
 VALU_PEAK_G = 256 * 4 * 2.4 / 2.5  # G wave-instructions/s for 1024 SIMDs at 2.4 GHz
+VALU_PEAK_GUIDE_G = 256 * 4 * 2.4 / 2.0  # the same against MI355X_MICROARCH.md's 2 cycles per wave64 VALU instruction
 
 
 def algorithmic_bytes(st, width, height, hit_bytes=12):
@@ -75,7 +76,8 @@ def cpu_baseline(scene, budget_s=None, threads=None):
     import ptamd
     if budget_s is None:
         budget_s = float(os.environ.get("PTX_BENCH_CPU_BUDGET", "15"))  # seconds of CPU work (tests shorten it)
-    threads = threads or min(os.cpu_count() or 1, 16)  # the GPU box's CPU share for one GPU is 16
+    available = os.cpu_count() or 1
+    threads = threads or min(available, 16)  # the GPU box's CPU share for one GPU is 16 (of `available` on the machine)
     p = ptamd.make_params(WIDTH, HEIGHT, spp=2, max_bounces=BOUNCES)
     _, st = ob.render(scene, p, seed_mode=ptamd.SEED_REFERENCE_GPU, threads=threads)
     per_spp = st.render_s / 2.0
@@ -84,7 +86,7 @@ def cpu_baseline(scene, budget_s=None, threads=None):
         p = ptamd.make_params(WIDTH, HEIGHT, spp=spp, max_bounces=BOUNCES)
         _, st = ob.render(scene, p, seed_mode=ptamd.SEED_REFERENCE_GPU, threads=threads)
     return {
-        "value": st.rays / st.render_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "value": st.rays / st.render_s / 1e6, "unit": "Mrays/s", "cores": threads, "cores_available": available, "kind": "port",
         "sample": f"scene {SCENE} {WIDTH}x{HEIGHT}, {spp} spp of {SPP}, {BOUNCES} bounces, "
                   f"{st.rays} rays in {st.render_s:.2f} s (oracle/pt_oracle.c, pthreads)",
     }
@@ -150,8 +152,11 @@ def main():
     # bookkeeping more often, longer ones make the frame's tail longer.  100 spp: 320.7 / 319.3 / 317.0 / 323.4 ms in
     # 20 / 25 / 34 / 40 streams; 50 spp: 165.6 / 160.7 / 168.2 ms in 10 / 17 / 25; 25 spp: 84.4 / 83.7 / 85.5 ms in
     # 7 / 9 / 13; 13 spp: 47.1 / 46.2 / 45.6 ms in 4 / 5 / 7 (profiles/r02/share_streams_ab.txt)
-    per_item = 2 if spp <= 16 else 3
-    sub_streams = max(1, min(args.sub_streams, (spp + per_item - 1) // per_item))
+    # EVERY rank passes the same sub_streams, derived from the largest share: the backend numbers a rank's streams
+    # part_index * sub_streams + k (ptx_backend.h), so ranks that passed different values would overlap (100 spp over 8 GPUs:
+    # shares 13,13,13,13,12,12,12,12 -> 7 and 6 streams -> rank 3 would own ids 21..27 and rank 4 ids 24..29).  A rank whose
+    # share is smaller than that simply runs fewer streams.
+    sub_streams = multigpu.streams_for_frame(frame_spp, world, args.sub_streams)
     # replicated on every GPU; the flattened arrays come from the on-disk cache when an earlier run (or
     # another rank) on this machine has built them (pt_host.h: pth_scene_create_cached)
     import tempfile
@@ -235,20 +240,39 @@ def main():
         # profiles/r02): per-ray figures of this kernel on this scene / resolution / bounce count, scaled to this
         # launch's exact ray count (the passes ran the 100-spp frame; a rank of an N-GPU job traces fewer samples)
         traffic = valu = l2_hit = lds_bytes = scratch = None
+        kernel_name = "ptx::pathKernel<1, false, true>" if os.environ.get("PTX_QUEUE", "1") == "0" else "ptx::poolKernel<false>"
+        counters_from = None   # which committed profile the counter figures come from
+        counters_note = "no committed counter profile (profiles/traffic.json)"
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 t = json.load(f)
-            if t.get("workload", "").startswith(f"scene{SCENE}_{WIDTH}x{HEIGHT}_") and t.get("workload", "").endswith(f"_{BOUNCES}b"):
+            same_workload = t.get("workload", "").startswith(f"scene{SCENE}_{WIDTH}x{HEIGHT}_") and t.get("workload", "").endswith(f"_{BOUNCES}b")
+            # the counters are per-ray figures of ONE build of ONE kernel with ONE stream count: reported only for that
+            if not same_workload:
+                counters_note = f"profiles/traffic.json holds {t.get('workload')}, not this workload"
+            elif t.get("build_id") != ptamd.build_id():
+                counters_note = (f"profiles/traffic.json was measured on build {t.get('build_id')}, the library timed here is "
+                                 f"{ptamd.build_id()}: counter figures withheld (tools/profile.sh + tools/make_traffic.py renew them)")
+            elif t.get("kernel") != kernel_name or t.get("sub_streams") != sub_streams:
+                counters_note = (f"profiles/traffic.json holds {t.get('kernel')} with {t.get('sub_streams')} streams, this run is "
+                                 f"{kernel_name} with {sub_streams}: counter figures withheld")
+            else:
+                counters_from = "profiles/traffic.json (" + t.get("source", "") + ", build " + t["build_id"] + ")"
+                counters_note = "per-ray counter figures of the committed rocprofv3 passes x this launch's exact ray count; times are live"
                 traffic = t["hbm_bytes_per_ray"] * stats.rays
                 l2_hit = t.get("l2_hit_rate")
                 lds_bytes = int(t["lds_bytes"]) if t.get("lds_bytes") is not None else None
                 scratch = int(t["scratch_size"]) if t.get("scratch_size") is not None else None
                 insts = t["valu_insts_per_ray"] * stats.rays
+                rate = insts / avg_kernel / 1e9
                 valu = {"bound": "VALU issue (wave-instructions)", "insts": insts, "per_ray": t["valu_insts_per_ray"],
-                        "achieved": insts / avg_kernel / 1e9, "peak": VALU_PEAK_G, "unit": "G wave-instructions/s",
-                        "frac": insts / avg_kernel / 1e9 / VALU_PEAK_G, "lane_utilisation": t.get("valu_lane_utilisation"),
-                        "source": "profiles/traffic.json (" + t.get("source", "") + ")"}
+                        "achieved": rate, "unit": "G wave-instructions/s",
+                        "peak": VALU_PEAK_G, "frac": rate / VALU_PEAK_G,
+                        "peak_is": "1024 SIMDs x 2.4 GHz / 2.5 cycles per instruction, measured (profiles/r01/ubench_valu2.txt)",
+                        "peak_guide": VALU_PEAK_GUIDE_G, "frac_guide": rate / VALU_PEAK_GUIDE_G,
+                        "peak_guide_is": "the same at 2 cycles per wave64 instruction (MI355X_MICROARCH.md)",
+                        "lane_utilisation": t.get("valu_lane_utilisation")}
         line = {
             "metric": "Mrays/s at 1500x800, 100spp, 6 bounces, Scene 1",
             "value": total_rays * args.steps / elapsed / 1e6,
@@ -273,10 +297,13 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": traffic / avg_kernel / 1e9 if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": traffic / avg_kernel / 1e9 / HBM_PEAK_GBS if traffic else None, "traffic": traffic,
+                # frac is COUNTER traffic / time / peak, not SURVEY 8(d)'s algorithmic bytes (those are l1_level below)
+                "basis": "counter", "from_committed_profile": counters_from is not None, "counters_from": counters_from,
+                "counters_note": counters_note, "build_id": ptamd.build_id(),
                 "traffic_is": "bytes requested by the L2 from the memory side (FETCH_SIZE x 2 + WRITE_SIZE), Infinity-Cache hits included",
                 "binding": "valu",
                 "l2_hit_rate": l2_hit, "lds_bytes_per_block": lds_bytes, "scratch_bytes_per_lane": scratch,
-                "kernel": "ptx::pathKernel<1, false, true>", "kernel_ms": avg_kernel * 1e3,
+                "kernel": kernel_name, "kernel_ms": avg_kernel * 1e3,
                 "l1_level": {"algorithmic_bytes": alg, "achieved": alg / avg_kernel / 1e9, "unit": "GB/s",
                              "note": "bytes the steps consume at the register file; re-served from L1 / L2 / Infinity Cache"},
                 "node_steps": stats.node_steps, "tri_tests": stats.tri_tests, "inst_entries": stats.inst_entries,

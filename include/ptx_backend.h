@@ -140,7 +140,11 @@ typedef struct ptx_params {
                               separate work item; partial sums are added in stream order.  The reference
                               has one serial stream per pixel, i.e. W*H independent chains; a chip with
                               more lanes than that idles through the tail of every frame.  0 or 1 = one
-                              stream (required for PTX_SEED_REFERENCE_GPU); at most 256. */
+                              stream (required for PTX_SEED_REFERENCE_GPU); at most 256.
+                              ALL PARTS OF ONE FRAME MUST PASS THE SAME VALUE (derive it from the largest share): stream ids
+                              are part_index * sub_streams + k, so parts that pass different values overlap and trace
+                              the same random streams twice.  A part whose share is smaller than sub_streams simply runs
+                              fewer streams. */
   uint32_t frame_spp;    /* samples per pixel of the WHOLE frame when this call renders a share of it (sample-slice
                               split: the sum of spp over all parts); 0 = this call is the whole frame (= spp).
                               The reference jitters the camera ray iff the frame has more than one sample
@@ -283,7 +287,8 @@ int ptx_check_wide_layout(const ptx_scene_desc* desc, uint64_t report[6]);
  * [2] of those, how many differ from the device's in any bit -- or, when the scene is so large that BLAS box corners
  *     stand in for the vertices, are not contained in the device's (must be 0), [3] TLAS nodes whose tight box is not
  * inside the reference's box or whose links changed (must be 0), [4] leaf boxes that do not hold the padded bounds
- * of one of their instances (must be 0), [5] mean leaf volume, tight / reference, in millionths.  device < 0: no GPU
+ * of one of their instances, plus recomputed instances whose padded box does not hold the bounds of their vertices taken in
+ * double through the exact inverse of inv_model -- the points the device's object-space test stands for (must be 0), [5] mean leaf volume, tight / reference, in millionths.  device < 0: no GPU
  * is touched, the bounds come from the host loop (small scenes: CPU tests of the refit). */
 int ptx_check_tight_tlas(const ptx_scene_desc* desc, int device, uint64_t report[6]);
 int ptx_selftest_reciprocal(int device, uint64_t* mismatches);
@@ -295,6 +300,14 @@ const char* ptx_last_error(void);
 
 /* Backend identification string: "ptx_backend <version> gfx950 HIP <runtime>" */
 const char* ptx_version(void);
+
+/* Hash of the sources and compiler flags this library was built from (tools/source_hash.py; "unstamped" for a build that
+ * did not pass it).  No counterpart in the reference: measurements kept beside the code (profiles/traffic.json) name the
+ * build they were taken on, and bench.py reports them only for that build. */
+const char* ptx_build_id(void);
+
+/* PTX_NOALLOC_SCRATCH_BYTES of the library that is loaded (callers that size requests from a binding, not from this header). */
+uint64_t ptx_noalloc_scratch_bytes(void);
 
 #ifdef __cplusplus
 }

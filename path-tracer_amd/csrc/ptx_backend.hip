@@ -734,6 +734,13 @@ const char* ptx_version(void) {
   return v.c_str();
 }
 
+#ifndef PTX_BUILD_ID
+#define PTX_BUILD_ID "unstamped"
+#endif
+const char* ptx_build_id(void) { return PTX_BUILD_ID; }
+
+uint64_t ptx_noalloc_scratch_bytes(void) { return (uint64_t)PTX_NOALLOC_SCRATCH_BYTES; }
+
 int ptx_device_count(int* count) {
   if (!count) return fail(PTX_EINVAL, "null argument");
   *count = 0;
@@ -795,7 +802,9 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
       std::vector<uint8_t> usable;
       if ((rc = deviceInstanceBounds(d, device, raw, usable))) return rc;
       std::vector<Box3> instBounds;
-      padBounds(raw.data(), usable, instBounds);
+      std::vector<float> allowance;
+      roundingAllowance(d, allowance);
+      padBounds(raw.data(), usable, allowance, instBounds);
       tlasTight = refitTlas(d, instBounds, nullptr);
     }
     const ptx_bvh_node* tlasForWide = tlasTight.empty() ? d->tlas_nodes : tlasTight.data();
@@ -1044,7 +1053,19 @@ int ptx_check_tight_tlas(const ptx_scene_desc* d, int device, uint64_t report[6]
     if (!same) report[2]++;
   }
   std::vector<Box3> inst;
-  padBounds(raw.data(), usable, inst);
+  std::vector<float> allowance;
+  roundingAllowance(d, allowance);
+  padBounds(raw.data(), usable, allowance, inst);
+  // the padded boxes hold the exact (double) bounds of what the device's object-space test stands for
+  for (uint32_t i = 0; i < n; i += step) {
+    double lo[3], hi[3];
+    if (!usable[i] || !exactInstanceBounds(d, i, lo, hi)) continue;
+    for (int k = 0; k < 3; k++)
+      if ((double)inst[i].mn[k] > lo[k] || (double)inst[i].mx[k] < hi[k]) {
+        report[4]++;
+        break;
+      }
+  }
   double ratio = 1.0;
   const std::vector<ptx_bvh_node> tight = refitTlas(d, inst, &ratio);
   for (uint32_t i = 0; i < d->tlas_node_count; i++) {

@@ -48,12 +48,37 @@ inline bool invertAffine(const float* m, double out[12]) {
 
 }  // namespace tight_detail
 
+// Rounding allowance per instance and axis, added to the pad below: the bounds are computed with the fp32 model matrix M
+// (the inverse of inv_model), and the device reaches the same points the other way round, through inv_model in fp32; the
+// rounding error of either is proportional to |M| |v|, not to where the result lands.  When large object-space coordinates
+// are cancelled by the translation (a mesh modelled far from its origin and moved back), the world-space result is small
+// while that error is not, so a pad relative to the box alone could cut hits off.  allowance = 2^-20 x (|M0| |x|max +
+// |M1| |y|max + |M2| |z|max + |M3|) over the geometry's object-space bounds (its BLAS root box).
+inline void roundingAllowance(const ptx_scene_desc* d, std::vector<float>& out /* 3 per instance */) {
+  out.assign((size_t)d->instance_count * 3u, 0.0f);
+  for (uint32_t n = 0; n < d->instance_count; n++) {
+    const ptx_instance& I = d->instances[n];
+    double M[12];
+    if (I.geometry_id >= d->geometry_count || !tight_detail::invertAffine(I.inv_model, M)) continue;
+    const ptx_geometry& G = d->geometries[I.geometry_id];
+    if (G.node_count == 0 || !d->blas_nodes) continue;
+    const ptx_bvh_node& root = d->blas_nodes[G.node_offset];
+    for (int a = 0; a < 3; a++) {
+      double e = std::fabs(M[4 * a + 3]);
+      for (int k = 0; k < 3; k++) e += std::fabs(M[4 * a + k]) * std::fmax(std::fabs((double)root.aabb_min[k]), std::fabs((double)root.aabb_max[k]));
+      const double allow = std::ldexp(e, -20);
+      out[3 * (size_t)n + a] = std::isfinite(allow) && allow < (double)FLT_MAX ? (float)allow : FLT_MAX;
+    }
+  }
+}
+
 // Raw bounds (min, max of the transformed vertices, from instanceBoundsKernel or from the host loop below) ->
-// boxes padded outwards.  The device reaches the same points through inv_model in fp32: the pad, 2^-16 of the box's
-// size and of its distance from the origin, is three orders of magnitude above that difference and far below the
-// 1/255 steps of the wide layout.  An instance without usable bounds (matrix not invertible, no triangles,
-// non-finite result) keeps an unbounded box: it is never tightened.
-inline void padBounds(const float* raw /* 6 per instance */, const std::vector<uint8_t>& usable, std::vector<Box3>& out) {
+// boxes padded outwards: by 2^-16 of the box's size and of its distance from the origin -- three orders of magnitude above
+// the fp32 difference for a mesh modelled around its origin, far below the 1/255 steps of the wide layout -- plus the
+// rounding allowance above.  An instance without usable bounds (matrix not invertible, no triangles, non-finite result)
+// keeps an unbounded box: it is never tightened.
+inline void padBounds(const float* raw /* 6 per instance */, const std::vector<uint8_t>& usable, const std::vector<float>& allowance,
+                      std::vector<Box3>& out) {
   out.resize(usable.size());
   for (size_t n = 0; n < usable.size(); n++) {
     Box3& B = out[n];
@@ -68,11 +93,35 @@ inline void padBounds(const float* raw /* 6 per instance */, const std::vector<u
     for (int a = 0; a < 3; a++) ok = ok && std::isfinite(lo3[a]) && std::isfinite(hi3[a]) && lo3[a] <= hi3[a];
     if (!ok) continue;
     for (int a = 0; a < 3; a++) {
-      const float pad = std::ldexp(std::fmax(hi3[a] - lo3[a], std::fmax(std::fabs(lo3[a]), std::fabs(hi3[a]))), -16) + FLT_MIN;
-      B.mn[a] = lo3[a] - pad;
-      B.mx[a] = hi3[a] + pad;
+      const float pad = std::ldexp(std::fmax(hi3[a] - lo3[a], std::fmax(std::fabs(lo3[a]), std::fabs(hi3[a]))), -16) + FLT_MIN +
+                        (allowance.size() > 3 * n + a ? allowance[3 * n + a] : 0.0f);
+      const float lo = lo3[a] - pad, hi = hi3[a] + pad;
+      if (std::isfinite(lo) && std::isfinite(hi)) {
+        B.mn[a] = lo;
+        B.mx[a] = hi;
+      }
     }
   }
+}
+
+// The bounds of instance n's transformed vertices in double, through the double inverse of inv_model: the points the
+// device's object-space test really stands for (ptx_check_tight_tlas holds the padded fp32 boxes against them).
+inline bool exactInstanceBounds(const ptx_scene_desc* d, uint32_t n, double lo[3], double hi[3]) {
+  const ptx_instance& I = d->instances[n];
+  double M[12];
+  if (!tight_detail::invertAffine(I.inv_model, M)) return false;
+  const ptx_geometry& G = d->geometries[I.geometry_id];
+  if (G.tri_count == 0) return false;
+  for (int a = 0; a < 3; a++) { lo[a] = DBL_MAX; hi[a] = -DBL_MAX; }
+  const float* v = d->triangles[G.tri_offset].v0;
+  const size_t nv = (size_t)G.tri_count * 3u;
+  for (size_t k = 0; k < nv; k++)
+    for (int a = 0; a < 3; a++) {
+      const double w = M[4 * a] * v[3 * k] + M[4 * a + 1] * v[3 * k + 1] + M[4 * a + 2] * v[3 * k + 2] + M[4 * a + 3];
+      lo[a] = w < lo[a] ? w : lo[a];
+      hi[a] = w > hi[a] ? w : hi[a];
+    }
+  return true;
 }
 
 // Host version of instanceBoundsKernel (ptx_check_tight_tlas: the device's bounds are checked against it).

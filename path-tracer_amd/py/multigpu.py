@@ -22,6 +22,23 @@ def split_samples(total_spp, world):
     return [base + (1 if r < extra else 0) for r in range(world)]
 
 
+def streams_for_frame(frame_spp, world, most=34):
+    """ptx_params.sub_streams for a frame whose samples are split over `world` ranks: ONE value for all ranks, from the
+    largest share -- work items of about three samples (two for shares of 16 spp or less: shorter items pay the per-item
+    bookkeeping more often, longer ones make the frame's tail longer; profiles/r02/share_streams_ab.txt), at most `most`.
+    The backend numbers a rank's streams part_index * sub_streams + k, so a value that differed between ranks would make
+    their stream ids overlap; a rank whose share is smaller than the value runs fewer streams."""
+    largest = split_samples(frame_spp, world)[0]
+    per_item = 2 if largest <= 16 else 3
+    return max(1, min(most, (largest + per_item - 1) // per_item))
+
+
+def stream_ids(frame_spp, world, most=34):
+    """The RNG stream ids every rank traces (what the backend does with streams_for_frame's value): for the tests."""
+    s = streams_for_frame(frame_spp, world, most)
+    return [[r * s + k for k in range(min(s, share))] for r, share in enumerate(split_samples(frame_spp, world))]
+
+
 class HipBackend:
     """Device buffers are torch CUDA tensors; kernels are launched through the C ABI on torch's
     current stream so that they are ordered with the RCCL collective."""

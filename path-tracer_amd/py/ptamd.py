@@ -245,17 +245,60 @@ def write_bmp(path, rgb):
 # ------------------------------------------------------------------------------------------------
 _backend = None
 
+
+class BackendError(RuntimeError):
+    pass
+
 BACKEND_SYMBOLS = [
     "ptx_device_count", "ptx_create", "ptx_render_counts", "ptx_render", "ptx_accumulate_device",
     "ptx_resolve_device", "ptx_counts_device", "ptx_measure", "ptx_last_kernel_seconds", "ptx_destroy",
     "ptx_last_error", "ptx_version", "ptx_check_wide_layout", "ptx_check_tight_tlas", "ptx_selftest_reciprocal", "ptx_render_counts_bgr8",
     "ptx_render_bgr8", "ptx_accumulate_device_noalloc", "ptx_render_multi", "ptx_render_counts_multi",
+    "ptx_build_id", "ptx_noalloc_scratch_bytes",
 ]
-NOALLOC_SCRATCH_BYTES = 128 << 20  # PTX_NOALLOC_SCRATCH_BYTES
+
+
+def noalloc_scratch_bytes():
+    """PTX_NOALLOC_SCRATCH_BYTES of the loaded library (asked of the library: no copy of the constant here)."""
+    return int(backend_lib().ptx_noalloc_scratch_bytes())
+
+
+def build_id():
+    """ptx_build_id() of the loaded library: hash of its sources and flags (tools/source_hash.py)."""
+    return backend_lib().ptx_build_id().decode()
+
+
+def hip_runtimes():
+    """Distinct libamdhip64 files mapped into this process (from /proc/self/maps)."""
+    found = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1] if "/" in line else ""
+                if "libamdhip64" in os.path.basename(path) and os.path.realpath(path) not in found:
+                    found.append(os.path.realpath(path))
+    except OSError:
+        pass
+    return found
+
+
+def check_hip_runtime():
+    """libptx_backend.so and PyTorch must share ONE HIP runtime.  The backend links the system's libamdhip64; the PyTorch
+    wheel bundles its own.  Whichever is loaded first serves both when the other is loaded later by the same soname -- that is
+    what `import torch` BEFORE ptamd.backend_lib() arranges (tests/conftest.py, bench.py, multigpu.HipBackend).  Loaded the
+    other way round, the process ends up with two runtimes: torch then reports "No HIP GPUs are available" and device
+    pointers of one runtime mean nothing to the other.  This says so instead."""
+    libs = hip_runtimes()
+    if len(libs) > 1:
+        raise BackendError("two HIP runtimes are mapped into this process (" + ", ".join(libs) + "): libptx_backend.so was loaded "
+                           "before PyTorch.  Import torch BEFORE the first ptamd.backend_lib() / DeviceScene in a process that "
+                           "uses both, so that the backend binds to the runtime torch has loaded (INTEGRATION.md section 5).")
 
 
 def backend_lib():
     global _backend
+    if _backend is not None:
+        check_hip_runtime()
     if _backend is None:
         # PTX_BACKEND_LIB selects an experimental build of the same library (tools/build_variants.sh)
         path = os.environ.get("PTX_BACKEND_LIB", os.path.join(LIB_DIR, "libptx_backend.so"))
@@ -283,14 +326,13 @@ def backend_lib():
         lib.ptx_destroy.restype = None
         lib.ptx_last_error.restype = C.c_char_p
         lib.ptx_version.restype = C.c_char_p
+        lib.ptx_build_id.restype = C.c_char_p
+        lib.ptx_noalloc_scratch_bytes.restype = C.c_uint64
         for name in BACKEND_SYMBOLS:
             getattr(lib, name)
         _backend = lib
+        check_hip_runtime()
     return _backend
-
-
-class BackendError(RuntimeError):
-    pass
 
 
 def _check(rc, what):

@@ -25,16 +25,45 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert "workload" in j["config"] and "model" not in j["config"]
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    # a fraction of the HBM peak made of measured memory-side bytes (profiles/traffic.json), not of L1-level bytes
-    assert 0.0 < r["frac"] <= 1.0 and r["traffic"] > 0 and abs(r["achieved"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
-    assert r["l1_level"]["algorithmic_bytes"] > r["traffic"] and r["memory_path"]["frac"] > 0
-    v = r["valu"]
-    assert 0.0 < v["frac"] <= 1.0 and 0.0 < v["lane_utilisation"] <= 1.0 and abs(v["insts"] - v["per_ray"] * j["config"]["rays_per_step"]) < 1.0
+    # (d) the fraction is counter traffic / time / peak, and says so; SURVEY 8(d)'s algorithmic bytes are l1_level
+    assert r["basis"] == "counter" and r["l1_level"]["algorithmic_bytes"] > 0 and r["memory_path"]["frac"] > 0
+    assert r["kernel"] == "ptx::poolKernel<false>" and r["kernel_ms"] > 0
+    # (a) counter figures are reported only next to the build they were measured on (profiles/traffic.json: build_id, kernel,
+    # stream count); this run is a 4-spp frame with two streams, so they must be withheld, with the reason
+    import ptamd
+    assert r["build_id"] == ptamd.build_id() and r["build_id"] != "unstamped"
+    assert r["from_committed_profile"] is False and r["frac"] is None and r["achieved"] is None and r["traffic"] is None and r["valu"] is None
+    assert "withheld" in r["counters_note"] or "measured on build" in r["counters_note"]
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert c["cores_available"] == os.cpu_count() and c["cores"] <= c["cores_available"]  # (c)
     # value = rays of the timed steps / wall time
     assert abs(j["value"] - j["config"]["rays_per_step"] / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * j["value"]
+
+
+def test_bench_line_of_the_headline_frame_carries_the_counter_figures_of_its_own_build():
+    """The default run (100 spp, 34 streams).  When profiles/traffic.json was measured on the library that is loaded, the line
+    carries the counter-derived figures, consistent with each other; when the sources have changed since, it withholds them."""
+    import ptamd
+    env = dict(os.environ, PTX_BENCH_CPU_BUDGET="1")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-reference-seeding"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
+    r = j["roofline"]
+    t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+    assert j["config"]["rng_streams_per_pixel_per_gpu"] == 34
+    if t.get("build_id") == ptamd.build_id():
+        assert r["from_committed_profile"] is True and t["build_id"] in r["counters_from"]
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] <= 1.0
+        assert r["traffic"] > 0 and abs(r["achieved"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+        assert r["l1_level"]["algorithmic_bytes"] > r["traffic"]
+        v = r["valu"]  # (b) both peaks, both fractions
+        assert 0.0 < v["frac_guide"] < v["frac"] <= 1.0 and abs(v["frac"] * v["peak"] - v["frac_guide"] * v["peak_guide"]) < 1e-6 * v["achieved"]
+        assert abs(v["peak_guide"] / v["peak"] - 1.25) < 1e-9
+        assert 0.0 < v["lane_utilisation"] <= 1.0 and abs(v["insts"] - v["per_ray"] * j["config"]["rays_per_step"]) < 1.0
+    else:
+        assert r["from_committed_profile"] is False and r["frac"] is None and r["valu"] is None and "measured on build" in r["counters_note"]
 
 
 def test_bench_two_ranks_rehearsed_on_one_gpu():

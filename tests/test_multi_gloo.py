@@ -114,3 +114,75 @@ def test_split_samples():
     for total in (1, 7, 100, 1024):
         for world in (1, 2, 4, 8):
             assert sum(multigpu.split_samples(total, world)) == total
+
+
+def test_stream_ids_of_all_ranks_are_disjoint():
+    """bench.py passes ONE sub_streams value on every rank (multigpu.streams_for_frame, from the largest share): the backend
+    numbers a rank's streams part_index * sub_streams + k, so per-rank values (7 for a 13-spp share, 6 for a 12-spp one) would
+    make rank 3 (ids 21..27) and rank 4 (24..29) trace the same streams twice."""
+    for frame_spp in (1, 3, 7, 12, 13, 34, 100, 101, 1024):
+        for world in (1, 2, 3, 4, 8):
+            ids = multigpu.stream_ids(frame_spp, world)
+            flat = [i for r in ids for i in r]
+            assert len(flat) == len(set(flat)), (frame_spp, world, ids)
+            s = multigpu.streams_for_frame(frame_spp, world)
+            for r, (mine, share) in enumerate(zip(ids, multigpu.split_samples(frame_spp, world))):
+                assert len(mine) == min(s, share) and all(r * s <= i < (r + 1) * s for i in mine)
+    assert multigpu.streams_for_frame(100, 8) == 7 and multigpu.streams_for_frame(100, 3) == 12 and multigpu.streams_for_frame(100, 1) == 34
+    # what round 2's bench.py did: a value per rank from its own share
+    per_rank = [[r * ((n + 1) // 2) + k for k in range((n + 1) // 2)] for r, n in enumerate(multigpu.split_samples(100, 8))]
+    flat = [i for r in per_rank for i in r]
+    assert len(flat) != len(set(flat))
+
+
+W8, H8 = 16, 12
+
+
+def _worker8(rank, world, port, outdir, cache_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()  # all eight ask for the same scene in the same fresh cache directory at once
+    scene = ptamd.HostScene(1, scatter_instances=64, cache_dir=cache_dir)
+    be = OracleBackend(scene)
+    c4 = multigpu.render_radiance(be, ptamd.make_params, W8, H8, 100, 6, rank, world, dist)    # BASELINE config 4: 13/12 spp
+    c5 = multigpu.render_radiance(be, ptamd.make_params, W8, H8, 1024, 8, rank, world, dist)   # config 5: 128 spp each
+    cnt = multigpu.render_counts(be, ptamd.make_params, W8, H8, rank, world, dist)
+    if rank == 0:
+        np.save(os.path.join(outdir, "c4.npy"), c4.numpy())
+        np.save(os.path.join(outdir, "c5.npy"), c5.numpy())
+        np.save(os.path.join(outdir, "cnt8.npy"), cnt.numpy())
+    with open(os.path.join(outdir, f"hit{rank}.txt"), "w") as f:
+        f.write("1" if scene.cache_hit else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+    scene.close()
+
+
+def test_eight_ranks_with_the_baseline_splits_and_one_cache_directory(tmp_path):
+    """World 8 on a tiny frame of scene 1: BASELINE config 4's split (100 spp -> 13,13,13,13,12,12,12,12) and config 5's
+    (1024 spp -> 128 each, 8 bounces), every rank building or loading the flattened scene in ONE fresh cache directory at the
+    same moment (bench.py does that on an 8-GPU node: pth_scene_create_cached must survive the race)."""
+    world = 8
+    port = 31500 + (os.getpid() % 2000)
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    mp.start_processes(_worker8, args=(world, port, str(tmp_path), str(cache)), nprocs=world, join=True, start_method="spawn")
+    scene = ptamd.HostScene(1, scatter_instances=64, cache_dir=str(cache))
+    assert scene.cache_hit  # a complete entry was left behind, whoever won the race
+
+    def expected(frame_spp, bounces):
+        acc = np.zeros((H8, W8, 4), dtype=np.float32)
+        for r, n in enumerate(multigpu.split_samples(frame_spp, world)):
+            p = ptamd.make_params(W8, H8, spp=n, max_bounces=bounces, seed_mode=ptamd.SEED_STREAM, part_index=r, part_count=world,
+                                  frame_spp=frame_spp)
+            a, _ = ob.accumulate(scene, p, seed_mode=ptamd.SEED_STREAM)
+            acc += a
+        assert (acc[..., 3] == frame_spp).all()
+        return ob.resolve(acc)
+
+    assert np.abs(np.load(tmp_path / "c4.npy") - expected(100, 6)).max() < 1e-5
+    assert np.abs(np.load(tmp_path / "c5.npy") - expected(1024, 8)).max() < 1e-5
+    full, _ = ob.render_counts(scene, ptamd.make_params(W8, H8))
+    assert np.array_equal(np.load(tmp_path / "cnt8.npy").astype(np.uint32), full)
+    scene.close()

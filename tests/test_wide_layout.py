@@ -135,3 +135,50 @@ def test_wide_and_binary_layouts_render_the_same_image(gpu_scenes, tmp_path):
         print(f"scene {preset}: {same * 100:.3f} % of pixels bit-identical, RMSE {rms:.2e}")
         assert same >= min_same
         assert rms < 5e-3
+
+
+def test_tight_pad_covers_a_mesh_modelled_far_from_its_origin():
+    """A mesh whose object-space coordinates are large (1e4) and whose instance moves it back to the origin: the fp32 rounding
+    error of the transform scales with |M| |v| = 1e4, not with the world-space result (a few units), so a pad relative to the
+    box alone (2^-16 of its size: round 2) does not cover what the device reaches through inv_model.  The pad carries an
+    allowance of 2^-20 (|M0| |x| + |M1| |y| + |M2| |z| + |M3|) (csrc/tight_bounds.hpp: roundingAllowance); the self-check
+    holds the padded box against the bounds taken in double."""
+    from test_gpu_analytic import FloorScene
+    off = np.array([10000.0, 0.0, 10000.0])
+    ca, sa = np.cos(0.7), np.sin(0.7)
+    rot_y = np.array([[ca, 0, sa, 0], [0, 1, 0, 0], [-sa, 0, ca, 0], [0, 0, 0, 1.0]])
+    back = np.eye(4)
+    back[:3, 3] = -off
+    model = rot_y @ back                     # move the mesh to the origin, then turn it
+    sc = FloorScene((0.5, 0.5, 0.5), (1.0, 1.0, 1.0), half=2.0, model=model)
+    for t in sc.tris:                        # the mesh itself sits at (1e4, 0, 1e4)
+        for v in (t.v0, t.v1, t.v2):
+            v[0] += off[0]
+            v[2] += off[2]
+    sc.blas[0].aabb_min[:] = (off[0] - 2.0, 0.0, off[2] - 2.0)
+    sc.blas[0].aabb_max[:] = (off[0] + 2.0, 0.0, off[2] + 2.0)
+    sc.tlas[0].aabb_min[:] = (-3.0, -1e-3, -3.0)
+    sc.tlas[0].aabb_max[:] = (3.0, 1e-3, 3.0)
+    lib = ptamd.backend_lib()
+    lib.ptx_check_tight_tlas.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    rep = (C.c_uint64 * 6)()
+    assert lib.ptx_check_tight_tlas(sc.desc_ptr, -1, rep) == 0, lib.ptx_last_error()
+    n, checked, differ, outside, misses, ratio = [int(v) for v in rep]
+    assert n == 1 and checked == 1 and differ == 0 and outside == 0 and misses == 0
+
+    # what round 2's pad would have done: fp32 bounds as the library computes them, padded by 2^-16 of the box
+    inv = np.array(list(sc.inst[0].inv_model), dtype=np.float32).reshape(4, 4).T.astype(np.float64)   # column-major -> rows
+    M = np.linalg.inv(inv)
+    verts = np.array([list(v) for t in sc.tris for v in (t.v0, t.v1, t.v2)], dtype=np.float32)
+    m32 = M[:3].astype(np.float32)
+    w32 = (m32[:, 0][None] * verts[:, 0:1] + m32[:, 1][None] * verts[:, 1:2]) + m32[:, 2][None] * verts[:, 2:3]
+    w32 = (w32 + m32[:, 3][None]).astype(np.float32)
+    exact = verts.astype(np.float64) @ M[:3, :3].T + M[:3, 3]
+    lo32, hi32 = w32.min(axis=0), w32.max(axis=0)
+    old_pad = np.maximum(hi32 - lo32, np.maximum(np.abs(lo32), np.abs(hi32))) * 2.0 ** -16
+    err = max(float((lo32 - exact.min(axis=0)).max()), float((exact.max(axis=0) - hi32).max()))
+    allowance = 2.0 ** -20 * (np.abs(M[:3, :3]) @ np.array([off[0] + 2.0, 0.0, off[2] + 2.0]) + np.abs(M[:3, 3]))
+    xz = [0, 2]                              # the floor is flat in y: nothing to bound there
+    print(f"fp32 bounds miss the exact ones by {err:.2e}; old pad {old_pad[xz].max():.2e}, allowance {allowance[xz].min():.2e}")
+    assert err > old_pad[xz].max()           # round 2's pad would have cut into the mesh
+    assert allowance[xz].min() > 10 * err    # the allowance covers the fp32 error with room to spare

@@ -59,3 +59,31 @@ def test_noalloc_refuses_what_does_not_fit(gpu_scenes):
     devs[1].accumulate_device_noalloc(hosts[1].camera, p, buf.data_ptr(), None)
     torch.cuda.synchronize()
     assert np.all(buf[..., 3].cpu().numpy() == 1)
+
+
+def test_noalloc_allocates_nothing(gpu_scenes):
+    """The property itself, not only the result: on a FRESH scene handle (no launch yet: its own overflow area and planes are
+    still unallocated, so a call that fell back to them would have to hipMalloc megabytes) the device's free memory is the
+    same before and after the call, while the allocating entry point on another fresh handle takes memory for the same frame."""
+    torch = pytest.importorskip("torch")
+    hosts, _ = gpu_scenes
+    p = ptamd.make_params(640, 400, spp=8, max_bounces=6, seed_mode=ptamd.SEED_STREAM, sub_streams=4)
+    out = torch.zeros((p.height, p.width, 4), dtype=torch.float32, device="cuda")
+    out2 = torch.zeros_like(out)
+    fresh, other = ptamd.DeviceScene(hosts[1].desc_ptr), ptamd.DeviceScene(hosts[1].desc_ptr)
+    try:
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        fresh.accumulate_device_noalloc(hosts[1].camera, p, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        assert free1 == free0, (free0, free1)
+        other.accumulate_device(hosts[1].camera, p, out2.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        free2, _ = torch.cuda.mem_get_info()
+        assert free2 < free1 - (4 << 20), (free1, free2)   # planes (16 MB) + stack overflow area + the chain records
+        assert np.array_equal(out.cpu().numpy(), out2.cpu().numpy())
+        assert ptamd.noalloc_scratch_bytes() == 256 << 20
+    finally:
+        fresh.close()
+        other.close()

@@ -18,9 +18,9 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
         r = list(csv.reader(open(f)))
         header = r[0]
-        rows += [x for x in r[1:] if "pathKernel" in x[header.index("Kernel_Name")]]
+        rows += [x for x in r[1:] if "pathKernel" in x[header.index("Kernel_Name")] or "poolKernel" in x[header.index("Kernel_Name")]]
     if header:
-        with open(os.path.join(dst, os.path.basename(d) + "_pathKernel.csv"), "w", newline="") as o:
+        with open(os.path.join(dst, os.path.basename(d) + "_radianceKernel.csv"), "w", newline="") as o:
             w = csv.writer(o)
             w.writerow(header)
             w.writerows(rows)

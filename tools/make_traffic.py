@@ -10,14 +10,18 @@ the path kernel's own passes show the same (pmc_tcc2).  So x2 is the bytes MOVED
 of 64-byte records USES half of them (FETCH_SIZE x 1.0 equals the known useful bytes of the gather), the other
 half of each line is useful only when the neighbouring record is wanted while the line is cached.  Infinity-Cache
 hits are included in the counter (the scene is 98 MB: most of this traffic never reaches HBM).
-usage: tools/make_traffic.py gpurun_out/prof_<tag> <spp> <rays per launch> [profiles/r02/calib/fetch_calibration.json]"""
+The file is stamped with the build id of the library the passes ran (prof_<tag>/build_id.txt, written by tools/profile.sh from
+ptx_build_id()), the kernel's name and the stream count: bench.py reports these figures only next to that build.
+usage: tools/make_traffic.py gpurun_out/prof_<tag> <spp> <rays per launch> <streams> [profiles/r02/calib/fetch_calibration.json]"""
 import json
 import os
 import subprocess
 import sys
 
 root, spp, rays = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
-calib_path = sys.argv[4] if len(sys.argv) > 4 else None
+streams = int(sys.argv[4])
+calib_path = sys.argv[5] if len(sys.argv) > 5 else None
+build_id = open(os.path.join(root, "build_id.txt")).read().strip()
 here = os.path.dirname(os.path.abspath(__file__))
 s = json.loads(subprocess.check_output([sys.executable, os.path.join(here, "pmc_summary.py"), root]))
 c, d = s["counters"], s["derived"]
@@ -31,7 +35,8 @@ fetch = d["fetch_bytes_raw"] * factor
 n128, n64, n32 = c.get("TCC_EA0_RDREQ_128B_sum"), c.get("TCC_EA0_RDREQ_64B_sum"), c.get("TCC_EA0_RDREQ_32B_sum")
 out = {
     "workload": f"scene1_1500x800_{spp}spp_6b",
-    "kernel": "ptx::pathKernel<1, false, true>",
+    "kernel": "ptx::poolKernel<false>" if "poolKernel" in s["dispatch"].get("Kernel_Name", "") else "ptx::pathKernel<1, false, true>",
+    "build_id": build_id, "sub_streams": streams,
     "rays_per_launch": rays,
     "fetch_size_raw_bytes": d["fetch_bytes_raw"], "fetch_factor": factor,
     "read_requests": {"all": c.get("TCC_EA0_RDREQ_sum"), "128B": n128, "64B": n64, "32B": n32},

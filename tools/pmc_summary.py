@@ -18,10 +18,11 @@ def main(root):
     meta = {}
     for f in glob.glob(os.path.join(root, "pmc_*", "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if "pathKernel<1, false" not in r["Kernel_Name"]:
-                continue  # the un-instrumented radiance instantiation only
+            if "pathKernel<1, false" not in r["Kernel_Name"] and "poolKernel<false>" not in r["Kernel_Name"]:
+                continue  # the un-instrumented radiance kernel only (poolKernel, or pathKernel with PTX_QUEUE=0)
+            meta["Kernel_Name"] = r["Kernel_Name"]
             counters[r["Counter_Name"]] += float(r["Counter_Value"])
-            meta = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size") if k in r}
+            meta.update({k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size") if k in r})
     out["counters"] = dict(counters)
     out["dispatch"] = meta
     c = counters

@@ -9,6 +9,7 @@ SPP=${2:-10}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
+python3 -c "import sys; sys.path.insert(0, '$ROOT/path-tracer_amd/py'); import ptamd; print(ptamd.build_id())" > $OUT/build_id.txt || exit 1
 cd /tmp && export TMPDIR=/tmp
 run() { # name, timeout, args...   (PROFILE_ONLY="pass pass ..." runs just those)
   local name=$1; shift; local to=$1; shift
