@@ -20,10 +20,12 @@ HOST_HDR = $(wildcard $(HOST)/*.hpp) include/ptx_backend.h include/pt_host.h
 HIP_SRC  = $(CSRC)/ptx_backend.hip
 HIP_HDR  = $(wildcard $(CSRC)/*.hpp) $(HOST)/ptmath.hpp $(HOST)/rng.hpp $(HOST)/colors.hpp include/ptx_backend.h
 
-all: host backend cli oracle
+all: host backend cli oracle sharedlibm
 
 host: $(LIB)/libpt_host.so
 backend: $(LIB)/libptx_backend.so
+# test build of the backend whose five libm calls come from tests/shared_libm/shared_libm.h (tests/test_gpu_shared_libm.py)
+sharedlibm: $(LIB)/libptx_backend_sharedlibm.so
 cli: $(PKG)/PathTracer
 oracle:
 	$(MAKE) -C oracle
@@ -37,6 +39,10 @@ $(LIB)/libptx_backend.so: $(HIP_SRC) $(HIP_HDR) tools/source_hash.py
 	@mkdir -p $(LIB)
 	$(HIPCC) $(HIPFLAGS) -DPTX_BUILD_ID=\"$(shell python3 tools/source_hash.py "$(HIPFLAGS)")\" -shared -o $@ $(HIP_SRC)
 
+$(LIB)/libptx_backend_sharedlibm.so: $(HIP_SRC) $(HIP_HDR) tests/shared_libm/shared_libm.h
+	@mkdir -p $(LIB)
+	$(HIPCC) $(HIPFLAGS) -DPTX_BUILD_ID=\"sharedlibm\" -DPTX_SHARED_LIBM='"../../tests/shared_libm/shared_libm.h"' -shared -o $@ $(HIP_SRC)
+
 $(PKG)/PathTracer: $(HOST)/main.cpp $(HOST)/gpu_render.cpp $(LIB)/libpt_host.so $(LIB)/libptx_backend.so
 	$(CXX) $(CXXFLAGS) -o $@ $(HOST)/main.cpp $(HOST)/gpu_render.cpp -L$(LIB) -lpt_host -lptx_backend \
 	    -Wl,-rpath,'$$ORIGIN/lib' -lpthread
@@ -45,4 +51,4 @@ clean:
 	rm -rf $(LIB) $(PKG)/PathTracer
 	$(MAKE) -C oracle clean
 
-.PHONY: all host backend cli oracle clean
+.PHONY: all host backend cli oracle sharedlibm clean

@@ -46,6 +46,21 @@
 #include "../include/ptx_backend.h"
 #include "pt_oracle.h"
 
+/* Test build libpt_oracle_sharedlibm.so (-DPT_SHARED_LIBM): cosf, sinf, atan2f, acosf and powf come from the header that the
+ * kernels' test build uses too, so that the radiance parity test can ask for identical bits (tests/shared_libm/shared_libm.h). */
+#ifdef PT_SHARED_LIBM
+#include "../tests/shared_libm/shared_libm.h"
+float oracle_shared_libm_probe(int fn, float x, float y) {
+  switch (fn) {
+    case 0: return cosf(x);
+    case 1: return sinf(x);
+    case 2: return atan2f(x, y);
+    case 3: return acosf(x);
+    default: return powf(x, y);
+  }
+}
+#endif
+
 typedef struct { float x, y, z; } v3;
 typedef struct { float x, y; } v2;
 

@@ -11,6 +11,14 @@
 #include "device_scene.hpp"
 #include "trace.hpp"
 
+// Test builds only (-DPTX_SHARED_LIBM=\"<path>/shared_libm.h\", Makefile target `sharedlibm`): the five libm calls below
+// (cosf, sinf, atan2f, acosf, powf) come from a header that the radiance parity test also compiles into its build of the CPU
+// checker, so that the two sides can be compared bit for bit (tests/test_gpu_shared_libm.py).  The shipped library calls the
+// device library.
+#ifdef PTX_SHARED_LIBM
+#include PTX_SHARED_LIBM
+#endif
+
 namespace ptx {
 
 using pt::vec2;

@@ -16,7 +16,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(REPO, "oracle", "libpt_oracle.so")
+        # PT_ORACLE_LIB selects a test build of the checker (libpt_oracle_sharedlibm.so: tests/test_gpu_shared_libm.py)
+        path = os.environ.get("PT_ORACLE_LIB", os.path.join(REPO, "oracle", "libpt_oracle.so"))
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: run `make oracle`")
         L = C.CDLL(path)
