@@ -27,7 +27,11 @@ def rmse(a, b):
     (2, (128, 96), 8, 4, 2e-3, 0.99),
     (2, (512, 512), 16, 4, 2e-3, 0.99),   # BASELINE.json configs[0] geometry
     (0, (150, 80), 8, 6, 2e-3, 0.99),
-    (1, (150, 80), 4, 6, 3e-2, 0.85),     # long specular chains amplify 1-ulp differences: looser
+    # scene 1 is looser for ONE reason, and it is shown, not assumed: glibc's and the device library's cosf / sinf / atan2f /
+    # acosf / powf differ by an ulp now and then, and a later bounce on a curved mirror turns that into another hit.  With one
+    # implementation of those five functions on both sides the accumulation buffers of this scene are identical BIT FOR BIT
+    # (tests/test_gpu_shared_libm.py: 0 of 48,000 pixels differ; 12,112 with each side's own libm).  "libm only".
+    (1, (150, 80), 4, 6, 3e-2, 0.85),
     (2, (64, 64), 1, 4, 2e-3, 0.99),      # spp == 1: no jitter (gpuRender.cu:134)
     (2, (33, 17), 5, 1, 2e-3, 0.99),      # one bounce: hit shading only, never the environment after a hit
 ])

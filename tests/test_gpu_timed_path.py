@@ -11,7 +11,10 @@ those code paths through the C ABI against the CPU oracle:
    roughness 0.05-0.2): a 1-ulp difference between glibc's and the device library's cosf/sinf/powf
    moves the next bounce, every curved mirror amplifies it, and after a few bounces the path hits
    another triangle (measured: 0.6 % of the paths at 6 bounces, 1.4 % at 8).  Such a path is another
-   sample of the SAME distribution, which is what the high-spp tests below check.
+   sample of the SAME distribution, which is what the high-spp tests below check.  That libm is the ONLY cause is shown by
+   tests/test_gpu_shared_libm.py: built with one implementation of those functions, oracle and kernels produce identical
+   accumulation buffers, bit for bit, on scenes 0-2 (and the shipped four-wide layout alone changes 18 of 48,000 pixels of
+   scene 1, none of scenes 0 and 2).  The tolerances here are "libm only".
  * different seeds, high spp (north_star: "a stated per-pixel RMSE at high spp"): the GPU frame with
    the bench's seeding (RNG sub-streams, wide layout) against the oracle with the reference CPU path's
    own seeding (`-d 1 -t 1`), scenes 0 and 1, 512 spp, 6 bounces.  Two independent estimates can only
