@@ -14,7 +14,7 @@ divides, colour-grades and tonemaps.  The scene is resident in HBM before the ti
 RNG streams: the reference seeds one serial stream per pixel (gpuRender.cu:130), i.e. 1.2 M
 independent chains of 100 samples for this frame -- fewer than four per lane of an MI355X, so the
 chip idles through a long tail.  The same sample-slice construct that splits a frame over GPUs is
-therefore also used inside a GPU: --sub-streams S (default 34: items of three samples) gives every pixel S streams of
+therefore also used inside a GPU: --sub-streams S (default 100: one stream per sample) gives every pixel S streams of
 100/S samples, each a work item of its own (ptx_params.sub_streams; parity against the sum of the
 oracle's streams in tests/test_gpu_radiance.py).  The frame with the reference's own seeding
 (S = 1, bit-compatible with gpuRender.cu's random sequence) is timed too and reported under
@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-seeding", action="store_true", help="skip the extra frame with the reference's seeding")
-    ap.add_argument("--sub-streams", type=int, default=34, help="most RNG streams per pixel and GPU (1 = the reference's seeding)")
+    ap.add_argument("--sub-streams", type=int, default=100, help="most RNG streams per pixel and GPU (1 = the reference's seeding)")
     ap.add_argument("--weak", action="store_true", help="weak scaling: 100 spp on every GPU (the job grows with N)")
     ap.add_argument("--spp", type=int, default=SPP, help=argparse.SUPPRESS)  # profiling runs only
     # rehearsal of the N > 1 path on a box with one GPU: every rank on cuda:0, buffers reduced through gloo
@@ -148,10 +148,6 @@ def main():
     import multigpu
     frame_spp = args.spp * world if args.weak else args.spp            # samples per pixel of the whole job
     spp = multigpu.split_samples(frame_spp, world)[rank]               # this rank's share
-    # Work items of about three samples (two for a share of 16 spp or less): shorter items pay the per-item
-    # bookkeeping more often, longer ones make the frame's tail longer.  100 spp: 320.7 / 319.3 / 317.0 / 323.4 ms in
-    # 20 / 25 / 34 / 40 streams; 50 spp: 165.6 / 160.7 / 168.2 ms in 10 / 17 / 25; 25 spp: 84.4 / 83.7 / 85.5 ms in
-    # 7 / 9 / 13; 13 spp: 47.1 / 46.2 / 45.6 ms in 4 / 5 / 7 (profiles/r02/share_streams_ab.txt)
     # EVERY rank passes the same sub_streams, derived from the largest share: the backend numbers a rank's streams
     # part_index * sub_streams + k (ptx_backend.h), so ranks that passed different values would overlap (100 spp over 8 GPUs:
     # shares 13,13,13,13,12,12,12,12 -> 7 and 6 streams -> rank 3 would own ids 21..27 and rank 4 ids 24..29).  A rank whose

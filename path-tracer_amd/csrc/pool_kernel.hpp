@@ -513,6 +513,7 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
       uint32_t pushVal = 0u;
       bool doPop = false;
       uint32_t push2 = 0u, push3 = 0u, nPush = 0u;
+      PTX_MARK("ENTER");
       if (isEnter) {
         // TLAS leaf: enter its first instance, keep the rest of the leaf (gpuFunctions.hpp:32-41)
         tlasLeaf = (nPrim > 1u) ? makeTlasLeafRef(first + 1u, nPrim - 1u) : 0u;
@@ -524,6 +525,7 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
         if (STATS) nInstEntries++;
         newRef = __float_as_uint(r3.y);  // InstXform::wideRootRef
       }
+      PTX_MARK("TRI");
       if (isTri) {
         // BLAS leaf, one triangle per step, in order, strict `<` (intersection.hpp:9-44, :112-122)
         TriRec tri;
@@ -535,6 +537,7 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
         doPop = nPrim == 1u;
         newRef = doPop ? top : makeLeafRef(first + 1u, nPrim - 1u);
       }
+      PTX_MARK("NODE");
       if (isNode) {
         // four-wide node (wide_bvh.hpp): nearest hit child next, the others deferred farthest first
         uint32_t sr[4];
@@ -547,6 +550,7 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
         nPush = doPop ? 0u : nHit - 1u;
         pushVal = sr[1]; push2 = sr[2]; push3 = sr[3];
       }
+      PTX_MARK("MERGE");
       {
         // leaving an instance: the pop that reaches a TLAS-level entry (pathKernel, v13)
         const bool leaving = doPop && inInst && (top < sc.tlasNodeEnd[1] || top >= kTlasLeafFlag);

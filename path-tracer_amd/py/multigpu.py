@@ -22,18 +22,19 @@ def split_samples(total_spp, world):
     return [base + (1 if r < extra else 0) for r in range(world)]
 
 
-def streams_for_frame(frame_spp, world, most=34):
+def streams_for_frame(frame_spp, world, most=100):
     """ptx_params.sub_streams for a frame whose samples are split over `world` ranks: ONE value for all ranks, from the
-    largest share -- work items of about three samples (two for shares of 16 spp or less: shorter items pay the per-item
-    bookkeeping more often, longer ones make the frame's tail longer; profiles/r02/share_streams_ab.txt), at most `most`.
-    The backend numbers a rank's streams part_index * sub_streams + k, so a value that differed between ranks would make
-    their stream ids overlap; a rank whose share is smaller than the value runs fewer streams."""
+    largest share -- one stream per sample (work items of one path), at most `most`.  With the pool kernel an item costs
+    nothing to start, and the shorter the items the more often a wave's lanes set out together through adjacent pixels:
+    100 spp took 313 / 304 / 297 / 293 / 289 ms in 8 / 20 / 34 / 67 / 100 streams (profiles/r03/pool_kernel_ab.txt; pathKernel
+    in round 2 was best at items of three samples).  The backend numbers a rank's streams part_index * sub_streams + k, so a
+    value that differed between ranks would make their stream ids overlap; a rank whose share is smaller than the value runs
+    fewer streams."""
     largest = split_samples(frame_spp, world)[0]
-    per_item = 2 if largest <= 16 else 3
-    return max(1, min(most, (largest + per_item - 1) // per_item))
+    return max(1, min(most, largest))
 
 
-def stream_ids(frame_spp, world, most=34):
+def stream_ids(frame_spp, world, most=100):
     """The RNG stream ids every rank traces (what the backend does with streams_for_frame's value): for the tests."""
     s = streams_for_frame(frame_spp, world, most)
     return [[r * s + k for k in range(min(s, share))] for r, share in enumerate(split_samples(frame_spp, world))]

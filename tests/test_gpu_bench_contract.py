@@ -42,7 +42,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 
 
 def test_bench_line_of_the_headline_frame_carries_the_counter_figures_of_its_own_build():
-    """The default run (100 spp, 34 streams).  When profiles/traffic.json was measured on the library that is loaded, the line
+    """The default run (100 spp, 100 streams).  When profiles/traffic.json was measured on the library that is loaded, the line
     carries the counter-derived figures, consistent with each other; when the sources have changed since, it withholds them."""
     import ptamd
     env = dict(os.environ, PTX_BENCH_CPU_BUDGET="1")
@@ -52,7 +52,7 @@ def test_bench_line_of_the_headline_frame_carries_the_counter_figures_of_its_own
     j = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
     r = j["roofline"]
     t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-    assert j["config"]["rng_streams_per_pixel_per_gpu"] == 34
+    assert j["config"]["rng_streams_per_pixel_per_gpu"] == 100
     if t.get("build_id") == ptamd.build_id():
         assert r["from_committed_profile"] is True and t["build_id"] in r["counters_from"]
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] <= 1.0

@@ -79,11 +79,11 @@ def test_sub_streams_on_the_timed_scene_match_the_oracle_streams(gpu_scenes, pre
     assert abs(int(st.rays) - int(rays)) <= max(8, int(0.02 * rays))
 
 
-@pytest.mark.parametrize("preset", [0, 1])
-def test_high_spp_agreement_with_the_cpu_path_seeding(gpu_scenes, preset):
+@pytest.mark.parametrize("preset,S", [(0, 16), (1, 16), (1, 256)])   # 256 streams of two samples: the bench's short items
+def test_high_spp_agreement_with_the_cpu_path_seeding(gpu_scenes, preset, S):
     torch = pytest.importorskip("torch")
     hosts, devs = gpu_scenes
-    W, H, SPP, B, S = 120, 64, 512, 6, 16
+    W, H, SPP, B = 120, 64, 512, 6
     cpu, _ = ob.render(hosts[preset], ptamd.make_params(W, H, spp=SPP, max_bounces=B), seed_mode=ob.SEED_REFERENCE_CPU,
                        threads=1)  # `-d 1 -t 1`: the only deterministic form of the reference CPU path
     frames = []

@@ -128,7 +128,8 @@ def test_stream_ids_of_all_ranks_are_disjoint():
             s = multigpu.streams_for_frame(frame_spp, world)
             for r, (mine, share) in enumerate(zip(ids, multigpu.split_samples(frame_spp, world))):
                 assert len(mine) == min(s, share) and all(r * s <= i < (r + 1) * s for i in mine)
-    assert multigpu.streams_for_frame(100, 8) == 7 and multigpu.streams_for_frame(100, 3) == 12 and multigpu.streams_for_frame(100, 1) == 34
+    assert multigpu.streams_for_frame(100, 8) == 13 and multigpu.streams_for_frame(100, 3) == 34 and multigpu.streams_for_frame(100, 1) == 100
+    assert multigpu.streams_for_frame(1024, 8) == 100 and multigpu.streams_for_frame(100, 1, most=34) == 34
     # what round 2's bench.py did: a value per rank from its own share
     per_rank = [[r * ((n + 1) // 2) + k for k in range((n + 1) // 2)] for r, n in enumerate(multigpu.split_samples(100, 8))]
     flat = [i for r in per_rank for i in r]
