@@ -41,6 +41,9 @@ namespace ptx {
 #ifndef PTX_POOL_SERVE_LANES
 #define PTX_POOL_SERVE_LANES 12    // finished lanes that make a wave deliver and refill
 #endif
+#ifndef PTX_POOL_BATCH
+#define PTX_POOL_BATCH 64          // pending chains that make a wave shade (a batch is at most 64: one chain per lane)
+#endif
 constexpr uint32_t kPStack = PTX_POOL_LDS_STACK;
 constexpr uint32_t kPParkSlots = 14u;        // dwords of traversal state parked around a shading batch
 constexpr uint32_t kPMaxChainsPerLane = 3u;  // slot ids are bytes; three lists of 192 bytes per wave fit beside the stack
@@ -265,7 +268,7 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
       PTX_PSTAMP(1);
 
       // ---- (B) shading batch: 64 chains are pending, or lanes would stay without a ray ----
-      const uint32_t nShade = births ? 64u : ((pendCount >= 64u || readyCount + hotCount < nWant) ? min(pendCount, 64u) : 0u);
+      const uint32_t nShade = births ? 64u : ((pendCount >= PTX_POOL_BATCH || readyCount + hotCount < nWant) ? min(pendCount, 64u) : 0u);
       if (nShade) {
         {
           // the wave's own rays wait in memory meanwhile (pathKernel: PTX_PARK; unconditional, or the compiler keeps the
@@ -514,6 +517,7 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
       bool doPop = false;
       uint32_t push2 = 0u, push3 = 0u, nPush = 0u;
       PTX_MARK("ENTER");
+      PTX_MARK("ENTER");
       if (isEnter) {
         // TLAS leaf: enter its first instance, keep the rest of the leaf (gpuFunctions.hpp:32-41)
         tlasLeaf = (nPrim > 1u) ? makeTlasLeafRef(first + 1u, nPrim - 1u) : 0u;
@@ -525,6 +529,7 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
         if (STATS) nInstEntries++;
         newRef = __float_as_uint(r3.y);  // InstXform::wideRootRef
       }
+      PTX_MARK("TRI");
       PTX_MARK("TRI");
       if (isTri) {
         // BLAS leaf, one triangle per step, in order, strict `<` (intersection.hpp:9-44, :112-122)
@@ -538,6 +543,7 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
         newRef = doPop ? top : makeLeafRef(first + 1u, nPrim - 1u);
       }
       PTX_MARK("NODE");
+      PTX_MARK("NODE");
       if (isNode) {
         // four-wide node (wide_bvh.hpp): nearest hit child next, the others deferred farthest first
         uint32_t sr[4];
@@ -550,6 +556,7 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
         nPush = doPop ? 0u : nHit - 1u;
         pushVal = sr[1]; push2 = sr[2]; push3 = sr[3];
       }
+      PTX_MARK("MERGE");
       PTX_MARK("MERGE");
       {
         // leaving an instance: the pop that reaches a TLAS-level entry (pathKernel, v13)

@@ -9,10 +9,16 @@ import torch  # before the backend (tests/conftest.py)
 torch.cuda.is_available()
 import ptamd
 spp4k = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-for scene_id, w, h, spp, b, streams in ((0, 1500, 800, 100, 6, 25), (2, 1500, 800, 100, 6, 25), (1, 3840, 2160, spp4k, 8, 16)):
+import multigpu
+cases = [(0, 1500, 800, 100, 6, multigpu.streams_for_frame(100, 1)), (0, 1500, 800, 100, 6, 1), (2, 1500, 800, 100, 6, multigpu.streams_for_frame(100, 1)),
+         (1, 3840, 2160, spp4k, 8, multigpu.streams_for_frame(8 * spp4k, 8)),      # one GPU's share of BASELINE's last configuration
+         (1, 1500, 800, 13, 6, multigpu.streams_for_frame(100, 8)), (1, 1500, 800, 25, 6, multigpu.streams_for_frame(100, 4)),
+         (1, 1500, 800, 50, 6, multigpu.streams_for_frame(100, 2))]                 # a rank's share of the bench frame over 8 / 4 / 2 GPUs
+for scene_id, w, h, spp, b, streams in cases:
     s = ptamd.HostScene(scene_id)
     d = ptamd.DeviceScene(s.desc_ptr)
-    p = ptamd.make_params(w, h, spp=spp, max_bounces=b, seed_mode=ptamd.SEED_STREAM, sub_streams=streams)
+    p = ptamd.make_params(w, h, spp=spp, max_bounces=b, seed_mode=ptamd.SEED_STREAM if streams > 1 else ptamd.SEED_REFERENCE_GPU,
+                          sub_streams=streams, frame_spp=100 if spp in (13, 25, 50) else 0, part_count=8 if spp == 13 else (4 if spp == 25 else (2 if spp == 50 else 1)))
     acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
     st = d.measure(s.camera, p)
     d.accumulate_device(s.camera, p, acc.data_ptr(), None)
