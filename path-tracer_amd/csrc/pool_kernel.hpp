@@ -55,7 +55,7 @@ constexpr uint32_t kPSlotBytes = kPWordArrays * 16u + 4u;
 struct PoolLayout {
   unsigned char* base;
   uint32_t chainsPerLane;  // 1 .. kPMaxChainsPerLane
-  uint32_t pad;
+  uint32_t staticPartition;  // 1: long items, and (nearly) all of them are taken in the first rounds: the waves keep pace by priority
 };
 struct PoolKernelArgs {  // the kernel arguments as the hardware lays them out (kernels.hpp: loadKernelArgument)
   DeviceScene sc;
@@ -102,6 +102,8 @@ __device__ __forceinline__ void poolStackWrite(const PoolStack& m, uint32_t slot
 // (global_load / global_store / global_atomic instead of the slower flat forms).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 __attribute__((address_space(1))) * GlobalQuads;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 __attribute__((address_space(1))) * GlobalPairs;
 #ifndef PTX_POOL_NT
 #define PTX_POOL_NT 0   // 1: chain records and parked state are read and written with the non-temporal hint
 #endif
@@ -113,6 +115,7 @@ typedef u32x4 __attribute__((address_space(1))) * GlobalQuads;
 #define PTX_PST(p, v) (*(p) = (v))
 #endif
 __device__ __forceinline__ u32x4 quad(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return (u32x4){a, b, c, d}; }
+__device__ __forceinline__ u32x2 pair(uint32_t a, uint32_t b) { return (u32x2){a, b}; }
 
 // The shading's copy of the scene description, re-read from the kernel-argument segment at a service so that its dozen
 // pointers do not occupy SGPRs through the traversal loop.  Every array lives in the one arena: each pointer is rebuilt as
@@ -144,9 +147,11 @@ __device__ __forceinline__ float bitsf(uint32_t u) { return __uint_as_float(u); 
 // Profiling builds (-DPTX_POOL_PROFILE, read with ptx_debug_pool_profile): per wave, summed over the grid --
 // [0..7] shader-clock ticks in: loop top, delivery, shading batch (with parking), refill, traversal step;
 // [8..] counts: 8 iterations, 9 services, 10 batches, 11 chains shaded, 12 rays delivered, 13 rays taken,
-// 14 lane-steps (lanes that step, summed over iterations), 15 lanes without a ray (summed over iterations)
+// 14 lane-steps (lanes that step, summed over iterations), 15 lanes without a ray (summed over iterations);
+// [16] the longest wave's ticks, [17] waves, [18] sum over waves of (ticks / 1024)^2
 #ifdef PTX_POOL_PROFILE
 __device__ unsigned long long gPoolProfile[32];
+__device__ unsigned long long gPoolWaves[8192 * 8];  // per wave: ticks, iterations, lane-steps, batches, chains shaded, ticks in traversal, start tick, services
 #define PTX_PSTAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); pprof[k] += now_ - plast; plast = now_; } while (0)
 #define PTX_PCOUNT(k, n) do { pprof[k] += (n); } while (0)
 #else
@@ -166,13 +171,6 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
   stk.area = reinterpret_cast<unsigned char*>(stackOverflow);
   stk.laneBytes = 4u * (blockIdx.x * kBlockThreads + threadIdx.x);
   stk.strideBytes = 4u * gridDim.x * kBlockThreads;
-#ifndef PTX_POOL_STATE_LDS
-#define PTX_POOL_STATE_LDS 0   // 1: list positions and urgency threshold in LDS between services (128 bytes more LDS: see below)
-#endif
-#if PTX_POOL_STATE_LDS
-  __shared__ uint32_t sWaveState[8u * (kBlockThreads / 64u)];
-  uint32_t* const waveState = sWaveState + (threadIdx.x >> 6) * 8u;
-#endif
   const uint32_t lane = threadIdx.x & 63u;
   uint8_t* const hotList = sLists + (threadIdx.x >> 6) * (3u * kPMaxSlots);
   uint8_t* const readyList = hotList + kPMaxSlots;
@@ -193,7 +191,8 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
   unsigned long long nBoxHits = 0;
   uint32_t count = 0;
 
-  // ---- wave state (uniform; kept in waveState[] between services) ----
+  // ---- wave state (uniform; the seven list positions are bytes, packed into two words between services so that they hold two
+  //      SGPRs through the traversal loop, not seven) ----
   //   birthsDone    rounds of 64 chains started so far (chainsPerLane of them)
   //   readyHead/Count, pendHead/Count, hotHead/Count    the three lists (rings of `slots` bytes)
   //   hotThreshold  Urgent chains.  With one RNG stream per pixel a pixel's samples are one serial chain, and the frame cannot
@@ -204,16 +203,31 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
   // LDS: 24 KB of stack + 3 x 192 bytes of lists per wave = 26,880 bytes per block, which is 21 allocation granules of
   // 1,280 bytes: six blocks per CU.  128 bytes more take a 22nd granule and the sixth block no longer fits, although the
   // occupancy query still answers six (measured: 301 -> 314 ms, the time of PTX_MAX_BLOCKS_PER_CU=5).
-#if PTX_POOL_STATE_LDS
-  if (lane < 8u) waveState[lane] = 0u;
-#else
-  uint32_t birthsDone = 0u, readyHead = 0u, readyCount = 0u, pendHead = 0u, pendCount = 0u, hotHead = 0u, hotCount = 0u;
+  uint32_t listsA = 0u;  // readyHead | readyCount << 8 | pendHead << 16 | pendCount << 24
+  uint32_t listsB = 0u;  // hotHead | hotCount << 8 | birthsDone << 16 | longest chain's remaining rays (of 256, decaying) << 24
   float hotThreshold = 0.0f;
+#ifndef PTX_POOL_PRIO
+#define PTX_POOL_PRIO 1            // waves of a static partition that lag behind the frame raise their issue priority (see the shading batch)
+#endif
+#ifndef PTX_POOL_PRIO_GAIN
+#define PTX_POOL_PRIO_GAIN 25.0f   // priority levels per unit of lag (a lag of 4 % of the wave's work = one level)
+#endif
+#ifndef PTX_POOL_PRIO_PUBLISH
+#define PTX_POOL_PRIO_PUBLISH 256u  // samples between two additions to the frame's count (a power of two)
+#endif
+#ifndef PTX_POOL_PRIO_C3
+#define PTX_POOL_PRIO_C3 115u      // shares (of 256) of the longest possible item that the wave's longest chain has ahead: levels 3, 2, 1
+#define PTX_POOL_PRIO_C2 77u
+#define PTX_POOL_PRIO_C1 38u
+#endif
+#if PTX_POOL_PRIO
+  uint32_t waveProgress = 0u;  // bits 0-29: samples this wave has finished; bits 30-31: the priority its lag asks for (one SGPR for both)
 #endif
 
 #ifdef PTX_POOL_PROFILE
   unsigned long long pprof[16] = {};
   unsigned long long plast = __builtin_readcyclecounter();
+  const unsigned long long pstart = plast;
 #endif
 
   for (;;) {
@@ -243,13 +257,8 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
       GlobalWords const instWords = (GlobalWords)(words + kPWordArrays * slots);               // H1 [slot]
       const uint32_t nPixels = fc.width * fc.height;
       const uint32_t totalWork = nPixels * fc.subStreams;
-#if PTX_POOL_STATE_LDS
-      uint32_t birthsDone = uniformWord(waveState[0]);
-      uint32_t readyHead = uniformWord(waveState[1]), readyCount = uniformWord(waveState[2]);
-      uint32_t pendHead = uniformWord(waveState[3]), pendCount = uniformWord(waveState[4]);
-      uint32_t hotHead = uniformWord(waveState[5]), hotCount = uniformWord(waveState[6]);
-      float hotThreshold = bitsf(uniformWord(waveState[7]));
-#endif
+      uint32_t readyHead = listsA & 255u, readyCount = (listsA >> 8) & 255u, pendHead = (listsA >> 16) & 255u, pendCount = listsA >> 24;
+      uint32_t hotHead = listsB & 255u, hotCount = (listsB >> 8) & 255u, birthsDone = (listsB >> 16) & 255u, longest = listsB >> 24;
       const bool births = birthsDone < q.chainsPerLane;
 
       // ---- (A) the finished rays: hit record to the chain's slot, chain to the pending list ----
@@ -292,7 +301,7 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
           vec3 ro(0.0f), rd(0.0f, 0.0f, -1.0f);
           uint32_t rng = 0u, pix = 0u, sample = 0u, bounce = 0u, segments = 0u;
           vec3 col(1.0f), sum(0.0f);
-          bool havePixel = false, pathEnded = true, live = valid, sumDirty = false;
+          bool havePixel = false, pathEnded = true, live = valid, sumDirty = false, endedSample = false;
           if (valid && !births) {
             const u32x4 a0 = PTX_PLD(words + (slot)), a1 = PTX_PLD(words + (slots + slot)), hh = PTX_PLD(words + (2u * slots + slot));
             const u32x4 pa = PTX_PLD(words + (3u * slots + slot)), pb = PTX_PLD(words + (4u * slots + slot));
@@ -313,6 +322,7 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
               if (STATS) nMisses++;
               col *= environmentLookup(scs, fc, rd);
             }
+            endedSample = pathEnded;
             if (pathEnded) {
               const u32x4 pc = PTX_PLD(words + (5u * slots + slot));
               sum = vec3(bitsf(pc.x), bitsf(pc.y), bitsf(pc.z)) + col;
@@ -401,6 +411,43 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
             if (nUrgent * 16u > nLive * 7u) hotThreshold = hotThreshold * 1.0625f + 0.25f;
             else if (nUrgent * 16u < nLive * 4u) hotThreshold *= 0.9375f;
           }
+#if PTX_POOL_PRIO
+          if (q.staticPartition != 0u) {
+            // Static partition (the reference's seeding at full size: every pixel is taken in the first rounds, nothing is left
+            // to pull): all waves hold the same amount of work, but the issue arbiter favours the older waves of a SIMD, so the
+            // young ones finish last on half-empty SIMDs (profiles/r03/wave_priority.txt: 380 ms against 336 ms).  Each wave
+            // compares the share of its samples it has finished with the share the whole frame has finished (one counter next to
+            // the work counter, added to every 256 samples, read here) and raises its priority (s_setprio) when it lags; the
+            // four levels are dithered from batch to batch so that the average follows the lag.  Scheduling only: no result
+            // depends on it.
+            GlobalWords const progress = workCounterS + 32;
+            const uint32_t nEnded = (uint32_t)__popcll(__ballot(endedSample));
+            const uint32_t before = waveProgress & 0x3FFFFFFFu, waveDone = before + nEnded;
+            const uint32_t publish = (waveDone & ~(PTX_POOL_PRIO_PUBLISH - 1u)) - (before & ~(PTX_POOL_PRIO_PUBLISH - 1u));  // the frame's count holds every wave's count rounded down
+            uint32_t fair = waveProgress >> 30;
+            if (publish != 0u) {
+              // the addition returns what the other waves have added so far: no other read of the counter (a load of it at every
+              // batch, from 6,144 waves, made the batches of scene 0 twice as long)
+              uint32_t frameDone = 0u;
+              if (lane == 0u) frameDone = __hip_atomic_fetch_add(progress, publish, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              frameDone = uniformWord(frameDone) + publish;
+              const float mine = (float)waveDone / ((float)slots * (float)fc.sppBase);
+              const float all = (float)frameDone / ((float)nPixels * (float)fc.sppBase);
+              const float levelF = 1.5f + (all - mine) * PTX_POOL_PRIO_GAIN + 0.25f * (float)(pendHead & 3u);
+              fair = levelF >= 3.0f ? 3u : (levelF <= 0.0f ? 0u : (uint32_t)levelF);
+            }
+            waveProgress = waveDone | (fair << 30);
+            // The other way to be late: one chain with more rays ahead than the wave's lanes can take off it (scenes where a few
+            // pixels cost many times the average).  Expected remaining rays of the wave's longest chain, as a share (of 256) of the
+            // most an item can have; the maximum over the chains of this batch, decaying, stands for the maximum over all chains.
+            float rem = live ? expectedLeft / (float)(itemSamples - sample + 1u) : 0.0f;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) rem = fmaxf(rem, __shfl_xor(rem, m, 64));
+            const float most = (float)(fc.sppBase + 1u) * (float)(fc.maxBounces + 1u);
+            const uint32_t now = min(255u, (uint32_t)(bitsf(uniformWord(fbits(rem))) * 256.0f / most));
+            longest = max(longest - min(longest, 1u + (longest >> 5)), now);
+          }
+#endif
           if (births) {
             birthsDone++;
           } else {
@@ -473,13 +520,19 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
           ref = sc.tlasRootRefWide;
         }
       }
-      PTX_PSTAMP(3);
-#if PTX_POOL_STATE_LDS
-      if (lane == 0u) {
-        waveState[0] = birthsDone; waveState[1] = readyHead; waveState[2] = readyCount; waveState[3] = pendHead;
-        waveState[4] = pendCount; waveState[5] = hotHead; waveState[6] = hotCount; waveState[7] = fbits(hotThreshold);
+#if PTX_POOL_PRIO
+      if (q.staticPartition != 0u) {
+        const uint32_t chainLevel = longest > PTX_POOL_PRIO_C3 ? 3u : (longest > PTX_POOL_PRIO_C2 ? 2u : (longest > PTX_POOL_PRIO_C1 ? 1u : 0u));
+        const uint32_t level = max(waveProgress >> 30, chainLevel);
+        if (level == 3u) __builtin_amdgcn_s_setprio(3);
+        else if (level == 2u) __builtin_amdgcn_s_setprio(2);
+        else if (level == 1u) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
       }
 #endif
+      PTX_PSTAMP(3);
+      listsA = readyHead | (readyCount << 8) | (pendHead << 16) | (pendCount << 24);
+      listsB = hotHead | (hotCount << 8) | (birthsDone << 16) | (longest << 24);
       // no ray in any lane, none ready, none pending, every round of births made: the wave's chains are all finished
       if (!births && birthsDone >= q.chainsPerLane && nTake == 0u && nWant == 64u && pendCount == 0u && readyCount == 0u && hotCount == 0u) break;
     }
@@ -592,8 +645,19 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
   }
 
 #ifdef PTX_POOL_PROFILE
-  if (lane == 0u)
+  if (lane == 0u) {
     for (int k = 0; k < 16; k++) atomicAdd(&gPoolProfile[k], pprof[k]);
+    // [16] longest wave, [17] waves, [18] sum of (duration / 1024)^2, [19..28] waves by duration in tenths of 2^30 ticks
+    const unsigned long long dur = __builtin_readcyclecounter() - pstart;
+    atomicMax(&gPoolProfile[16], dur);
+    atomicAdd(&gPoolProfile[17], 1ull);
+    atomicAdd(&gPoolProfile[18], (dur >> 10) * (dur >> 10));
+    const uint32_t wv = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
+    if (wv < 8192u) {
+      unsigned long long* o = gPoolWaves + wv * 8u;
+      o[0] = dur; o[1] = pprof[8]; o[2] = pprof[14]; o[3] = pprof[10]; o[4] = pprof[11]; o[5] = pprof[4]; o[6] = pstart; o[7] = pprof[9];
+    }
+  }
 #endif
   if (STATS) {
     atomicAdd(&stats->rays, (unsigned long long)nRays);

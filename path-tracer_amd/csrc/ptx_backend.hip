@@ -591,7 +591,10 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
     if (getenv("PTX_DEBUG_LAUNCH"))
       fprintf(stderr, "[ptx] poolKernel: %u blocks (%d CUs), %u chains per lane, scatter %u, %u streams, %zu bytes of chain records\n", plan.blocks,
               s->numCus, q.chainsPerLane, fc.scatterMul, fc.subStreams, bytes);
+    // static partition: (nearly) every item is taken in the first rounds (pool_kernel.hpp, PTX_POOL_PRIO)
+    q.staticPartition = (fc.sppBase >= 16u && (uint64_t)work <= (uint64_t)threads * q.chainsPerLane + threads / 4u) ? 1u : 0u;
     HIP_TRY(hipMemsetAsync(scr.workCounter, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(scr.workCounter + 32, 0, sizeof(uint32_t), stream));
     HIP_TRY(hipEventRecord(s->evStart, stream));
     kernel<<<dim3(plan.blocks), dim3(kBlockThreads), 0, stream>>>(s->dev, fc, q, scr.workCounter, direct ? (void*)dOut : (void*)scr.planes, s->dStats,
                                                                    scr.overflow);
@@ -1529,11 +1532,20 @@ extern "C" int ptx_debug_queue_counters(ptx_scene* s, unsigned int* out16) {
 
 #ifdef PTX_POOL_PROFILE
 // Profiling builds only: reads and clears the pool kernel's region profile (pool_kernel.hpp).
-extern "C" int ptx_debug_pool_profile(unsigned long long* out16) {
+extern "C" int ptx_debug_pool_profile(unsigned long long* out32) {
   if (hipDeviceSynchronize() != hipSuccess) return -2;
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ptx::gPoolProfile), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(ptx::gPoolProfile), sizeof(unsigned long long) * 32) != hipSuccess) return -2;
   unsigned long long zero[32] = {};
   if (hipMemcpyToSymbol(HIP_SYMBOL(ptx::gPoolProfile), zero, sizeof(zero)) != hipSuccess) return -2;
+  return 0;
+}
+#endif
+
+#ifdef PTX_POOL_PROFILE
+extern "C" int ptx_debug_pool_waves(unsigned long long* out, unsigned waves) {
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (waves > 8192u) waves = 8192u;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ptx::gPoolWaves), sizeof(unsigned long long) * 8u * waves) != hipSuccess) return -2;
   return 0;
 }
 #endif

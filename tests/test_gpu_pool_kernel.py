@@ -38,6 +38,7 @@ CASES = [  # scene, width, height, spp, bounces, streams
     (1, 1, 1, 7, 6, 0),        # one pixel: 63 of a wave's lanes never get a chain
     (1, 200, 120, 40, 6, 0),   # long items: scattered over the waves, three chains per lane, urgent list (pool_kernel.hpp)
     (1, 200, 120, 40, 6, 13),
+    (1, 1500, 800, 16, 6, 0),  # the reference's seeding at full size: a static partition, every wave of the chip in the priority feedback
 ]
 
 
