@@ -159,11 +159,10 @@ __device__ unsigned long long gPoolWaves[8192 * 8];  // per wave: ticks, iterati
 #define PTX_PCOUNT(k, n) do {} while (0)
 #endif
 
-template <bool STATS>
-__global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES) poolKernel(DeviceScene sc, FrameConstants fcArg, PoolLayout qArg,
-                                                                                uint32_t* workCounter, void* __restrict__ outRaw,
-                                                                                DeviceStats* stats, uint32_t* stackOverflow) {
-  (void)fcArg; (void)qArg; (void)workCounter; (void)outRaw;
+// PACED: the launch is a static partition (PoolLayout::staticPartition) and the waves keep pace by priority, see the shading
+// batch; a kernel of its own (pacedPoolKernel) so that the other launches do not carry its registers through their service section.
+template <bool STATS, bool PACED>
+__device__ __forceinline__ void poolBody(const DeviceScene& sc, DeviceStats* stats, uint32_t* stackOverflow) {
   __shared__ uint32_t sStack[kPStack * kBlockThreads];
   __shared__ uint8_t sLists[3u * kPMaxSlots * (kBlockThreads / 64u)];  // per wave: ready (urgent), ready (others), pending
   PoolStack stk;
@@ -203,12 +202,12 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
   // LDS: 24 KB of stack + 3 x 192 bytes of lists per wave = 26,880 bytes per block, which is 21 allocation granules of
   // 1,280 bytes: six blocks per CU.  128 bytes more take a 22nd granule and the sixth block no longer fits, although the
   // occupancy query still answers six (measured: 301 -> 314 ms, the time of PTX_MAX_BLOCKS_PER_CU=5).
-  uint32_t listsA = 0u;  // readyHead | readyCount << 8 | pendHead << 16 | pendCount << 24
-  uint32_t listsB = 0u;  // hotHead | hotCount << 8 | birthsDone << 16 | longest chain's remaining rays (of 256, decaying) << 24
+  // (PACED only: its extra state would otherwise push a lane mask of the traversal loop out of the SGPRs; the plain kernel is
+  // better off with the seven as they are -- tools/kernel_resources.py --regions shows either choice)
+  uint32_t listsA = 0u;  // PACED: readyHead | readyCount << 8 | pendHead << 16 | pendCount << 24
+  uint32_t listsB = 0u;  // PACED: hotHead | hotCount << 8 | birthsDone << 16 | longest chain's remaining rays (of 256, decaying) << 24
+  uint32_t kBirthsDone = 0u, kReadyHead = 0u, kReadyCount = 0u, kPendHead = 0u, kPendCount = 0u, kHotHead = 0u, kHotCount = 0u;  // !PACED
   float hotThreshold = 0.0f;
-#ifndef PTX_POOL_PRIO
-#define PTX_POOL_PRIO 1            // waves of a static partition that lag behind the frame raise their issue priority (see the shading batch)
-#endif
 #ifndef PTX_POOL_PRIO_GAIN
 #define PTX_POOL_PRIO_GAIN 25.0f   // priority levels per unit of lag (a lag of 4 % of the wave's work = one level)
 #endif
@@ -220,9 +219,7 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
 #define PTX_POOL_PRIO_C2 77u
 #define PTX_POOL_PRIO_C1 38u
 #endif
-#if PTX_POOL_PRIO
-  uint32_t waveProgress = 0u;  // bits 0-29: samples this wave has finished; bits 30-31: the priority its lag asks for (one SGPR for both)
-#endif
+  uint32_t waveProgress = 0u;  // PACED; bits 0-29: samples this wave has finished; bits 30-31: the priority its lag asks for (one SGPR for both)
 
 #ifdef PTX_POOL_PROFILE
   unsigned long long pprof[16] = {};
@@ -257,8 +254,12 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
       GlobalWords const instWords = (GlobalWords)(words + kPWordArrays * slots);               // H1 [slot]
       const uint32_t nPixels = fc.width * fc.height;
       const uint32_t totalWork = nPixels * fc.subStreams;
-      uint32_t readyHead = listsA & 255u, readyCount = (listsA >> 8) & 255u, pendHead = (listsA >> 16) & 255u, pendCount = listsA >> 24;
-      uint32_t hotHead = listsB & 255u, hotCount = (listsB >> 8) & 255u, birthsDone = (listsB >> 16) & 255u, longest = listsB >> 24;
+      uint32_t readyHead = kReadyHead, readyCount = kReadyCount, pendHead = kPendHead, pendCount = kPendCount;
+      uint32_t hotHead = kHotHead, hotCount = kHotCount, birthsDone = kBirthsDone, longest = 0u;
+      if (PACED) {
+        readyHead = listsA & 255u; readyCount = (listsA >> 8) & 255u; pendHead = (listsA >> 16) & 255u; pendCount = listsA >> 24;
+        hotHead = listsB & 255u; hotCount = (listsB >> 8) & 255u; birthsDone = (listsB >> 16) & 255u; longest = listsB >> 24;
+      }
       const bool births = birthsDone < q.chainsPerLane;
 
       // ---- (A) the finished rays: hit record to the chain's slot, chain to the pending list ----
@@ -411,8 +412,7 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
             if (nUrgent * 16u > nLive * 7u) hotThreshold = hotThreshold * 1.0625f + 0.25f;
             else if (nUrgent * 16u < nLive * 4u) hotThreshold *= 0.9375f;
           }
-#if PTX_POOL_PRIO
-          if (q.staticPartition != 0u) {
+          if (PACED) {
             // Static partition (the reference's seeding at full size: every pixel is taken in the first rounds, nothing is left
             // to pull): all waves hold the same amount of work, but the issue arbiter favours the older waves of a SIMD, so the
             // young ones finish last on half-empty SIMDs (profiles/r03/wave_priority.txt: 380 ms against 336 ms).  Each wave
@@ -447,7 +447,6 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
             const uint32_t now = min(255u, (uint32_t)(bitsf(uniformWord(fbits(rem))) * 256.0f / most));
             longest = max(longest - min(longest, 1u + (longest >> 5)), now);
           }
-#endif
           if (births) {
             birthsDone++;
           } else {
@@ -520,8 +519,7 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
           ref = sc.tlasRootRefWide;
         }
       }
-#if PTX_POOL_PRIO
-      if (q.staticPartition != 0u) {
+      if (PACED) {
         const uint32_t chainLevel = longest > PTX_POOL_PRIO_C3 ? 3u : (longest > PTX_POOL_PRIO_C2 ? 2u : (longest > PTX_POOL_PRIO_C1 ? 1u : 0u));
         const uint32_t level = max(waveProgress >> 30, chainLevel);
         if (level == 3u) __builtin_amdgcn_s_setprio(3);
@@ -529,10 +527,14 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
         else if (level == 1u) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
       }
-#endif
       PTX_PSTAMP(3);
-      listsA = readyHead | (readyCount << 8) | (pendHead << 16) | (pendCount << 24);
-      listsB = hotHead | (hotCount << 8) | (birthsDone << 16) | (longest << 24);
+      if (PACED) {
+        listsA = readyHead | (readyCount << 8) | (pendHead << 16) | (pendCount << 24);
+        listsB = hotHead | (hotCount << 8) | (birthsDone << 16) | (longest << 24);
+      } else {
+        kReadyHead = readyHead; kReadyCount = readyCount; kPendHead = pendHead; kPendCount = pendCount;
+        kHotHead = hotHead; kHotCount = hotCount; kBirthsDone = birthsDone;
+      }
       // no ray in any lane, none ready, none pending, every round of births made: the wave's chains are all finished
       if (!births && birthsDone >= q.chainsPerLane && nTake == 0u && nWant == 64u && pendCount == 0u && readyCount == 0u && hotCount == 0u) break;
     }
@@ -668,6 +670,21 @@ __global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES)
     atomicAdd(&stats->misses, (unsigned long long)nMisses);
     atomicAdd(&stats->boxHits, nBoxHits);
   }
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES) poolKernel(DeviceScene sc, FrameConstants fcArg, PoolLayout qArg,
+                                                                                uint32_t* workCounter, void* __restrict__ outRaw,
+                                                                                DeviceStats* stats, uint32_t* stackOverflow) {
+  (void)fcArg; (void)qArg; (void)workCounter; (void)outRaw;  // read from the kernel-argument segment where they are needed (PoolKernelArgs)
+  poolBody<STATS, false>(sc, stats, stackOverflow);
+}
+template <bool STATS>
+__global__ void __launch_bounds__(kBlockThreads, STATS ? 5 : PTX_POOL_MIN_WAVES) pacedPoolKernel(DeviceScene sc, FrameConstants fcArg, PoolLayout qArg,
+                                                                                     uint32_t* workCounter, void* __restrict__ outRaw,
+                                                                                     DeviceStats* stats, uint32_t* stackOverflow) {
+  (void)fcArg; (void)qArg; (void)workCounter; (void)outRaw;
+  poolBody<STATS, true>(sc, stats, stackOverflow);
 }
 
 }  // namespace ptx

@@ -568,7 +568,7 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
     return (int)PTX_OK;
   };
   // The pool kernel (pool_kernel.hpp): a private pool of chains per wave, shading in batches of 64.
-  auto goPool = [&](auto kernel) {
+  auto goPool = [&](auto kernel, auto pacedKernel) {
     LaunchPlan plan;
     Scratch scr;
     int rc = planLaunch(s, kernel, fc, true, kPStack, 1u, plan, kPParkSlots);
@@ -591,13 +591,19 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
     if (getenv("PTX_DEBUG_LAUNCH"))
       fprintf(stderr, "[ptx] poolKernel: %u blocks (%d CUs), %u chains per lane, scatter %u, %u streams, %zu bytes of chain records\n", plan.blocks,
               s->numCus, q.chainsPerLane, fc.scatterMul, fc.subStreams, bytes);
-    // static partition: (nearly) every item is taken in the first rounds (pool_kernel.hpp, PTX_POOL_PRIO)
+    // static partition: long items, and (nearly) all of them are taken in the first rounds: pacedPoolKernel (pool_kernel.hpp, PACED);
+    // PTX_POOL_PACED=0 launches poolKernel all the same (A/B; same frames)
     q.staticPartition = (fc.sppBase >= 16u && (uint64_t)work <= (uint64_t)threads * q.chainsPerLane + threads / 4u) ? 1u : 0u;
+    if (const char* e = getenv("PTX_POOL_PACED")) if (e[0] == '0') q.staticPartition = 0u;
     HIP_TRY(hipMemsetAsync(scr.workCounter, 0, sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(scr.workCounter + 32, 0, sizeof(uint32_t), stream));
     HIP_TRY(hipEventRecord(s->evStart, stream));
-    kernel<<<dim3(plan.blocks), dim3(kBlockThreads), 0, stream>>>(s->dev, fc, q, scr.workCounter, direct ? (void*)dOut : (void*)scr.planes, s->dStats,
-                                                                   scr.overflow);
+    if (q.staticPartition)
+      pacedKernel<<<dim3(plan.blocks), dim3(kBlockThreads), 0, stream>>>(s->dev, fc, q, scr.workCounter, direct ? (void*)dOut : (void*)scr.planes,
+                                                                          s->dStats, scr.overflow);
+    else
+      kernel<<<dim3(plan.blocks), dim3(kBlockThreads), 0, stream>>>(s->dev, fc, q, scr.workCounter, direct ? (void*)dOut : (void*)scr.planes, s->dStats,
+                                                                     scr.overflow);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->evStop, stream));
     s->lastStream = stream;
@@ -670,7 +676,7 @@ int launchRadiance(ptx_scene* s, const FrameConstants& fc, float* dOut, bool res
 #ifdef PTX_EXPERIMENT_QUEUES
   if (wide && owner == ScratchOwner::handle && radianceKernelChoice() == 2) return stats ? goQueue(queueKernel<true>) : goQueue(queueKernel<false>);
 #endif
-  if (wide && owner == ScratchOwner::handle && radianceKernelChoice() == 1) return stats ? goPool(poolKernel<true>) : goPool(poolKernel<false>);
+  if (wide && owner == ScratchOwner::handle && radianceKernelChoice() == 1) return stats ? goPool(poolKernel<true>, pacedPoolKernel<true>) : goPool(poolKernel<false>, pacedPoolKernel<false>);
   if (wide) return stats ? go(pathKernel<kModeRadiance, true, true>, kLdsStack) : go(pathKernel<kModeRadiance, false, true>, kLdsStack);
   return stats ? go(pathKernel<kModeRadiance, true, false>, kLdsStack) : go(pathKernel<kModeRadiance, false, false>, kLdsStack);
 }
@@ -981,6 +987,7 @@ int ptx_create(const ptx_scene_desc* d, int device, ptx_scene** out) {
   if (!rc) rc = persistentGrid(s, radianceKernel<false>, blocks);
 #endif
   if (!rc) rc = persistentGrid(s, poolKernel<false>, blocks);
+  if (!rc) rc = persistentGrid(s, pacedPoolKernel<false>, blocks);
   if (!rc) rc = persistentGrid(s, pathKernel<kModeRadiance, false, true>, blocks);
   if (!rc) rc = persistentGrid(s, pathKernel<kModeRadiance, false, false>, blocks);
   if (rc) {

@@ -39,7 +39,7 @@ def kernels(text):
         if m:
             name = "pathKernel<%s, %s, %s>" % ("radiance" if m.group(1) == "1" else "counts",
                                                "stats" if m.group(2) == "1" else "plain", "wide" if m.group(3) == "1" else "binary")
-        m = re.match(r"_ZN3ptx(\d+)(queueKernel|poolKernel)ILb(\d)E", name)
+        m = re.match(r"_ZN3ptx(\d+)(queueKernel|poolKernel|pacedPoolKernel)ILb(\d)E", name)
         if m:
             name = "%s<%s>" % (m.group(2), "stats" if m.group(3) == "1" else "plain")
         f["waves_per_simd"] = min(8, 512 // max(f["vgpr_count"], 1) if f["vgpr_count"] > 64 else 8)
@@ -85,3 +85,4 @@ if __name__ == "__main__":
         for region, line in scratch_by_region(text):
             print(f"  {region:12s} {line}")
         print("poolKernel spill traffic by region:", pool_spill_ops_by_region(text))
+        print("pacedPoolKernel spill traffic by region:", pool_spill_ops_by_region(text, "_ZN3ptx15pacedPoolKernelILb0E"))
