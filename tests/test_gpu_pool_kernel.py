@@ -53,10 +53,11 @@ def test_pool_kernel_equals_path_kernel_bit_for_bit(gpu_scenes, scene, w, h, spp
     assert np.array_equal(a, b), int((a != b).any(axis=2).sum())
 
 
-@pytest.mark.parametrize("env", [{"PTX_POOL_CHAINS": "1"}, {"PTX_POOL_CHAINS": "3", "PTX_SCATTER": "1"}, {"PTX_POOL_CHAINS": "2", "PTX_SCATTER": "0"}])
+@pytest.mark.parametrize("env", [{"PTX_POOL_CHAINS": "1"}, {"PTX_POOL_CHAINS": "3", "PTX_SCATTER": "1"}, {"PTX_POOL_CHAINS": "2", "PTX_SCATTER": "0"},
+                                 {"PTX_POOL_PACED": "0"}])  # the default of this frame is pacedPoolKernel (a static partition)
 def test_pool_kernel_result_does_not_depend_on_its_scheduling(gpu_scenes, env):
-    """Chains per lane, the order in which pixels are handed to the waves and which chains are served first decide WHEN a
-    ray is traced, never what it returns."""
+    """Chains per lane, the order in which pixels are handed to the waves, which chains are served first and which waves the
+    issue arbiter prefers decide WHEN a ray is traced, never what it returns."""
     hosts, devs = gpu_scenes
     p = ptamd.make_params(320, 200, spp=24, max_bounces=6)
     ref, _ = render_with(devs[1], hosts[1], p, "path")
